@@ -1,0 +1,443 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE ITSELF.
+
+Only runs in the build container, where /root/reference exists (it is read-only and never travels
+to the GPU box); the .npz files it writes are plain data (inputs + expected outputs) and are what
+the tests read.  Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+How the reference is imported:
+  * `colorlog` is not installed -> a 10-line stand-in module is put in sys.modules first;
+  * MCTSNode._next_state (core/MCTS_alphazero.py:99) calls next_state with 2 arguments although every
+    game takes 3 -> patched at call time to pass the node's own player (the reference is not edited);
+  * RNG draws are captured as data: every Dirichlet sample (core/MCTS_alphazero.py:187) is recorded,
+    and every torch.multinomial call (training/self_play.py:74) is replayed as
+    argmax(weights / Exponential(1) draws) from the same generator state, asserted equal to torch's
+    own answer, and the exponential draws recorded;
+  * every model forward is recorded as a table  nn_input bytes -> (logits, value).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("AZ_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    stub = types.ModuleType("colorlog")
+
+    class ColoredFormatter(logging.Formatter):
+        def __init__(self, fmt=None, datefmt=None, style="%", log_colors=None, reset=True,
+                     secondary_log_colors=None, **kw):
+            super().__init__(None, datefmt)
+
+    stub.ColoredFormatter = ColoredFormatter
+    stub.StreamHandler = logging.StreamHandler
+    sys.modules["colorlog"] = stub
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    logging.disable(logging.CRITICAL)
+    import core.MCTS_alphazero as M  # noqa
+
+    M.MCTSNode._next_state = lambda self, a: self.game_cls.next_state(self.state, a, self.player)
+    return M
+
+
+M = _import_reference()
+from examples.tictactoe.game import TicTacToeGame  # noqa: E402
+from examples.tictactoe.model import TicTacToeModel  # noqa: E402
+from examples.dots_and_boxes.game import DotsAndBoxesGame  # noqa: E402
+from examples.dots_and_boxes.model import DotsAndBoxesModel  # noqa: E402
+from examples.gomoku.game import GomokuGame  # noqa: E402
+from examples.gomoku.model import GomokuModel  # noqa: E402
+from nn_models.base import BaseModel  # noqa: E402
+from training.self_play import ChessArena  # noqa: E402
+import training.self_play as SP  # noqa: E402
+
+torch.set_num_threads(1)
+
+
+# ----------------------------------------------------------------------------- recorders ----
+class Recorder:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.noise = []
+        self.expo = []
+        self.mult_w = []
+        self.mult_a = []
+        self.eval_in = []
+        self.eval_logits = []
+        self.eval_value = []
+        self.sel_trace = []  # per search: list per sim of chosen actions
+        self.priors = []  # every _get_prior output, in call order
+        self._cur = None
+
+
+REC = Recorder()
+
+_RealDirichlet = M.Dirichlet
+
+
+class RecDirichlet(_RealDirichlet):
+    def sample(self, *a, **k):
+        s = super().sample(*a, **k)
+        REC.noise.append(s.reshape(-1).numpy().copy())
+        return s
+
+
+M.Dirichlet = RecDirichlet
+
+_real_multinomial = torch.multinomial
+
+
+def rec_multinomial(w, num_samples=1, *a, **k):
+    st = torch.get_rng_state()
+    e = torch.empty_like(w).exponential_(1)
+    mine = int(torch.argmax(w / e, dim=-1).reshape(-1)[0])
+    torch.set_rng_state(st)
+    out = _real_multinomial(w, num_samples, *a, **k)
+    assert int(out.reshape(-1)[0]) == mine, "multinomial != argmax(w/expo)"
+    REC.expo.append(e.reshape(-1).numpy().copy())
+    REC.mult_w.append(w.reshape(-1).numpy().copy())
+    REC.mult_a.append(mine)
+    return out
+
+
+torch.multinomial = rec_multinomial
+
+_real_select = M.MCTSNode.select
+
+
+def rec_select(self, c_puct=1.0):
+    ch = _real_select(self, c_puct)
+    act = next(a for a, c in self.children.items() if c is ch)
+    REC._cur.append(act)
+    return ch
+
+
+M.MCTSNode.select = rec_select
+
+_real_get_prior = M.MCTS._get_prior
+
+
+def rec_get_prior(self, policy, mask, use):
+    p = _real_get_prior(self, policy, mask, use)
+    REC.priors.append(p.reshape(-1).numpy().copy())
+    return p
+
+
+M.MCTS._get_prior = rec_get_prior
+
+_real_backward = M.MCTS._bacaward
+
+
+def rec_backward(self, node, value):
+    REC.sel_trace.append(list(REC._cur))
+    REC._cur = []
+    return _real_backward(self, node, value)
+
+
+M.MCTS._bacaward = rec_backward
+
+
+class RecModel(torch.nn.Module):
+    """Wraps a reference model; logs every forward."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward(self, x):
+        p, v = self.inner(x)
+        REC.eval_in.append(x.reshape(-1).numpy().astype(np.int8).copy())
+        REC.eval_logits.append(p.reshape(-1).numpy().copy())
+        REC.eval_value.append(np.float32(v.reshape(-1)[0].item()))
+        return p, v
+
+
+class Gomoku9Model(BaseModel):
+    """The reference has no 9x9 net (GomokuModel hard-codes 15); a small net of the same contract."""
+
+    def __init__(self):
+        super().__init__()
+        self._s = torch.nn.Sequential(torch.nn.Conv2d(9, 8, 3, padding=1), torch.nn.ReLU())
+        self._p = torch.nn.Sequential(torch.nn.Flatten(1), torch.nn.Linear(8 * 81, 81))
+        self._v = torch.nn.Sequential(torch.nn.Flatten(1), torch.nn.Linear(8 * 81, 1), torch.nn.Tanh())
+
+    @property
+    def shared_layers(self):
+        return self._s
+
+    def policy_head(self, x):
+        return self._p(x)
+
+    def value_head(self, x):
+        return self._v(x)
+
+
+# ----------------------------------------------------------------------------- rules KATs ----
+def playout(game_cls, rng, script=None, max_moves=400):
+    """Random (or scripted) playout through the STATIC interface; returns per-step arrays."""
+    s = game_cls.initial_state()
+    p = 1
+    acts, states, nps, masks, terms, winners = [], [], [], [], [], []
+    masks0 = game_cls.legal_action_mask(s).reshape(-1).numpy().copy()
+    k = 0
+    while not game_cls.is_terminal(s) and k < max_moves:
+        m = game_cls.legal_action_mask(s).reshape(-1).numpy()
+        legal = np.nonzero(m)[0]
+        a = int(script[k]) if script is not None and k < len(script) else int(rng.choice(legal))
+        s, p2 = game_cls.next_state(s, a, p)
+        acts.append(a)
+        states.append(s.reshape(-1).numpy().astype(np.int8).copy())
+        nps.append(p2)
+        masks.append(game_cls.legal_action_mask(s).reshape(-1).numpy().copy())
+        terms.append(bool(game_cls.is_terminal(s)))
+        w = game_cls._get_winner(s)
+        winners.append(0 if w is None else int(w))
+        p = p2
+        k += 1
+        if script is not None and k >= len(script):
+            break
+    return dict(actions=np.array(acts, np.int32), states=np.array(states, np.int8),
+                next_players=np.array(nps, np.int32), masks=np.array(masks, np.float32),
+                terminal=np.array(terms, np.bool_), winner=np.array(winners, np.int32), mask0=masks0)
+
+
+def rules_fixture(name, game_cls, scripts, n_random, seed):
+    rng = np.random.default_rng(seed)
+    out = {}
+    idx = 0
+    for sc in scripts:
+        for k, v in playout(game_cls, rng, script=sc).items():
+            out[f"g{idx}_{k}"] = v
+        idx += 1
+    for _ in range(n_random):
+        for k, v in playout(game_cls, rng).items():
+            out[f"g{idx}_{k}"] = v
+        idx += 1
+    out["n_games"] = np.int32(idx)
+    # illegal-move behaviour: occupied cell / out of range raise ValueError
+    s = game_cls.initial_state()
+    s, _ = game_cls.next_state(s, 0, 1)
+    for a, key in ((0, "err_occupied"), (-1, "err_neg"), (10 ** 6, "err_big")):
+        try:
+            game_cls.next_state(s, a, -1)
+            out[key] = np.bool_(False)
+        except ValueError:
+            out[key] = np.bool_(True)
+    np.savez_compressed(os.path.join(OUT, f"rules_{name}.npz"), **out)
+    print("rules", name, idx, "games")
+
+
+def gomoku_scripts(n):
+    def rc(r, c):
+        return r * n + c
+
+    S = []
+    # horizontal five by P1 on row 0 (P2 plays row n-1)
+    S.append([x for i in range(5) for x in (rc(0, i), rc(n - 1, i))][:9])
+    # vertical five on last column
+    S.append([x for i in range(5) for x in (rc(i, n - 1), rc(i, 0))][:9])
+    # main diagonal five ending in the bottom-right corner
+    S.append([x for i in range(5) for x in (rc(n - 5 + i, n - 5 + i), rc(0, i))][:9])
+    # anti-diagonal five touching the left edge
+    S.append([x for i in range(5) for x in (rc(i, 4 - i), rc(n - 1, i))][:9])
+    # six in a row: P1 plays 0,1,2,4,5 then 3  (P2 elsewhere, no five)
+    p1 = [rc(2, 0), rc(2, 1), rc(2, 2), rc(2, 4), rc(2, 5), rc(2, 3)]
+    p2 = [rc(n - 1, 0), rc(n - 2, 2), rc(n - 1, 4), rc(n - 2, 6), rc(n - 1, 8)]
+    S.append([x for i in range(6) for x in ((p1[i], p2[i]) if i < 5 else (p1[i],))])
+    # P2 wins (second player) with a vertical five
+    S.append([x for i in range(5) for x in (rc(n - 1, 2 * i if 2 * i < n else i), rc(i + 1, 3))][:10])
+    return S
+
+
+def make_rules():
+    ttt_scripts = [[0, 3, 1, 4, 2], [0, 1, 3, 4, 8, 7], [0, 1, 2, 4, 3, 5, 7, 6, 8], [4, 0, 2, 6, 3, 5, 1, 7, 8]]
+    rules_fixture("tictactoe", TicTacToeGame, ttt_scripts, 40, 1)
+    # DAB: a chain that completes two boxes with one edge (double completion, extra turns)
+    # H edges: a=r*3+c (r 0..3, c 0..2); V edges: a=12+r*4+c (r 0..2, c 0..3).
+    # boxes (0,0) and (0,1) share V(0,1)=13: lay all their other edges first, then 13 completes both.
+    dab_double = [0, 1, 3, 4, 12, 14, 13]
+    dab_scripts = [dab_double, list(range(24)), list(range(23, -1, -1))]
+    rules_fixture("dab", DotsAndBoxesGame, dab_scripts, 40, 2)
+    GomokuGame.BOARD_SIZE = 15
+    rules_fixture("gomoku15", GomokuGame, gomoku_scripts(15), 6, 3)
+    GomokuGame.BOARD_SIZE = 9
+    rules_fixture("gomoku9", GomokuGame, gomoku_scripts(9), 10, 4)
+    GomokuGame.BOARD_SIZE = 15
+
+
+# ----------------------------------------------------------------------------- search KATs ----
+def random_position(game_cls, n_moves, rng):
+    g = game_cls()
+    for _ in range(n_moves):
+        m = g.get_legal_mask().reshape(-1).numpy()
+        if g.step(int(rng.choice(np.nonzero(m)[0]))):
+            return None
+    return g
+
+
+def search_case(game_cls, model, n_moves, num_sim, use_dir, rng, seed):
+    while True:
+        g = random_position(game_cls, n_moves, rng)
+        if g is not None:
+            break
+    REC.reset()
+    REC._cur = []
+    torch.manual_seed(seed)
+    mcts = M.MCTS(game_cls)
+    hist = g.get_history()
+    root = g.get_state()
+    # capture root children stats through a wrapped _bacaward: easier -> rerun a hook on the last root
+    roots = []
+    real_node_init = M.MCTSNode.__init__
+
+    def node_init(self, *a, **k):
+        real_node_init(self, *a, **k)
+        if self.parent is None:
+            roots.append(self)
+
+    M.MCTSNode.__init__ = node_init
+    try:
+        pi = mcts.search(RecModel(model), root, g.get_player(), history_state=hist,
+                         num_simulation=num_sim, use_Dirichlet=use_dir)
+    finally:
+        M.MCTSNode.__init__ = real_node_init
+    rootn = roots[0]
+    A = pi.shape[1]
+    visits = np.zeros(A, np.int32)
+    cq = np.zeros(A, np.float64)
+    for a, c in rootn.children.items():
+        visits[a] = c.visits
+        cq[a] = c.value
+    D = max(len(t) for t in REC.sel_trace) + 1
+    trace = np.full((num_sim, D), -1, np.int32)
+    for i, t in enumerate(REC.sel_trace):
+        trace[i, 0] = len(t)
+        trace[i, 1:1 + len(t)] = t
+    return dict(
+        root_state=root.reshape(-1).numpy().astype(np.int8), root_player=np.int32(g.get_player()),
+        history=hist.reshape(-1).numpy().astype(np.int8), num_sim=np.int32(num_sim),
+        noise=(np.array(REC.noise[0], np.float32) if use_dir else np.zeros(0, np.float32)),
+        pi=pi.reshape(-1).numpy().copy(), visits=visits, child_q=cq,
+        root_prior=rootn.prior.reshape(-1).numpy().copy(), root_value=np.float64(rootn.value),
+        root_visits=np.int32(rootn.visits), trace=trace,
+        priors=np.array(REC.priors, np.float32), eval_in=np.array(REC.eval_in, np.int8),
+        eval_logits=np.array(REC.eval_logits, np.float32), eval_value=np.array(REC.eval_value, np.float32))
+
+
+def make_search():
+    rng = np.random.default_rng(7)
+    cases = []
+
+    def add(tag, game_cls, model, n_moves, num_sim, use_dir, seed):
+        c = search_case(game_cls, model, n_moves, num_sim, use_dir, rng, seed)
+        cases.append((tag, c))
+        print("search", tag, "moves", n_moves, "sims", num_sim, "maxdepth", c["trace"][:, 0].max())
+
+    torch.manual_seed(100)
+    ttt = TicTacToeModel().eval()
+    for i, (nm, ns, ud) in enumerate([(0, 50, True), (2, 50, True), (4, 80, True), (5, 120, False), (6, 50, True)]):
+        add(f"tictactoe_{i}", TicTacToeGame, ttt, nm, ns, ud, 200 + i)
+    torch.manual_seed(101)
+    dab = DotsAndBoxesModel().eval()
+    for i, (nm, ns, ud) in enumerate([(0, 80, True), (6, 80, True), (14, 80, True), (18, 200, False), (20, 80, True)]):
+        add(f"dab_{i}", DotsAndBoxesGame, dab, nm, ns, ud, 300 + i)
+    torch.manual_seed(102)
+    gmk = GomokuModel().eval()
+    GomokuGame.BOARD_SIZE = 15
+    for i, (nm, ns, ud) in enumerate([(0, 60, True), (12, 60, True), (30, 40, False)]):
+        add(f"gomoku15_{i}", GomokuGame, gmk, nm, ns, ud, 400 + i)
+    torch.manual_seed(103)
+    g9 = Gomoku9Model().eval()
+    GomokuGame.BOARD_SIZE = 9
+    for i, (nm, ns, ud) in enumerate([(0, 100, True), (10, 200, True), (40, 100, False)]):
+        add(f"gomoku9_{i}", GomokuGame, g9, nm, ns, ud, 500 + i)
+    GomokuGame.BOARD_SIZE = 15
+    out = {"tags": np.array([t for t, _ in cases])}
+    for t, c in cases:
+        for k, v in c.items():
+            out[f"{t}__{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "search.npz"), **out)
+
+
+# --------------------------------------------------------------------------- self-play KATs ----
+class ListPool:
+    def __init__(self):
+        self.items = []
+
+    def put_tupule_experience(self, exp):
+        self.items.append(exp)
+
+
+def selfplay_case(game_cls, model_cls, num_sim, tao, seed, model_seed):
+    import config
+
+    old = M.MCTS.search.__defaults__
+    # TRAIN_NUM_SIMULATION is bound as a default argument (core/MCTS_alphazero.py:134)
+    M.MCTS.search.__defaults__ = (old[0], num_sim) + tuple(old[2:])
+    try:
+        torch.manual_seed(model_seed)
+        arena = ChessArena(model_cls, game_cls, torch.device("cpu"))
+        arena.model = RecModel(arena.model)
+        REC.reset()
+        REC._cur = []
+        torch.manual_seed(seed)
+        pool = ListPool()
+        arena.self_play(tao, pool)
+    finally:
+        M.MCTS.search.__defaults__ = old
+    T = len(pool.items)
+    states = np.array([e[0].reshape(-1).numpy() for e in pool.items]).astype(np.int8)
+    pis = np.array([e[1].reshape(-1).numpy() for e in pool.items], np.float32)
+    zs = np.array([float(e[2][0]) for e in pool.items], np.float32)
+    assert pool.items[0][0].shape[0] == 1 and pool.items[0][2].shape == (1,)
+    return dict(num_sim=np.int32(num_sim), tao=np.float32(tao), plies=np.int32(T),
+                noise=np.array(REC.noise, np.float32), expo=np.array(REC.expo, np.float32),
+                actions=np.array(REC.mult_a, np.int32), put_states=states, put_pis=pis, put_z=zs,
+                state_shape=np.array(pool.items[0][0].shape, np.int32),
+                pi_shape=np.array(pool.items[0][1].shape, np.int32),
+                eval_in=np.array(REC.eval_in, np.int8), eval_logits=np.array(REC.eval_logits, np.float32),
+                eval_value=np.array(REC.eval_value, np.float32))
+
+
+def dedup_evals(c):
+    """Keep one table row per distinct NN input (the same position is re-evaluated across moves)."""
+    seen, keep = set(), []
+    for i, row in enumerate(c["eval_in"]):
+        k = row.tobytes()
+        if k not in seen:
+            seen.add(k)
+            keep.append(i)
+    for k in ("eval_in", "eval_logits", "eval_value"):
+        c[k] = c[k][keep]
+    return c
+
+
+def make_selfplay():
+    cases = []
+    for i, (tao, seed) in enumerate([(1.0, 11), (1.0, 12), (0.5, 13)]):
+        cases.append((f"tictactoe_{i}", dedup_evals(selfplay_case(TicTacToeGame, TicTacToeModel, 50, tao, seed, 100))))
+    for i, (tao, seed) in enumerate([(1.0, 21), (0.7, 22)]):
+        cases.append((f"dab_{i}", dedup_evals(selfplay_case(DotsAndBoxesGame, DotsAndBoxesModel, 40, tao, seed, 101))))
+    out = {"tags": np.array([t for t, _ in cases])}
+    for t, c in cases:
+        print("selfplay", t, "plies", int(c["plies"]), "evals", len(c["eval_in"]))
+        for k, v in c.items():
+            out[f"{t}__{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "selfplay.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_rules()
+    make_search()
+    make_selfplay()

@@ -1,0 +1,118 @@
+"""Pins the CPU oracle (oracle/az_oracle.c) to the reference: every golden vector in tests/golden/
+was produced by running the reference itself (tests/golden/make_golden.py).
+
+Bars: rules, visit counts, per-simulation descent paths, chosen moves, z and NN-input tensors are
+bit-exact; priors / pi / Q are compared at 1e-5 relative (north_star), because softmax's expf and the
+order of Tensor.sum() live inside torch, not in the reference's sources.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from .conftest import GOLDEN, game_of, load_cases
+
+RULES = [("tictactoe", 0, 3), ("dab", 1, 3), ("gomoku15", 2, 15), ("gomoku9", 2, 9)]
+
+
+@pytest.mark.parametrize("name,game,n", RULES)
+def test_rules_kat(oracle, name, game, n):
+    z = np.load(os.path.join(GOLDEN, f"rules_{name}.npz"))
+    d = oracle.dims(game, n)
+    for g in range(int(z["n_games"])):
+        s = np.zeros(d["numel"], np.float32)
+        assert np.array_equal(oracle.legal_mask(game, n, s), z[f"g{g}_mask0"])
+        player = 1
+        for k, a in enumerate(z[f"g{g}_actions"]):
+            s, player = oracle.next_state(game, n, s, int(a), player)
+            assert np.array_equal(s.astype(np.int8), z[f"g{g}_states"][k]), (g, k)
+            assert player == z[f"g{g}_next_players"][k]
+            assert np.array_equal(oracle.legal_mask(game, n, s), z[f"g{g}_masks"][k])
+            term, winner = oracle.status(game, n, s)
+            assert term == bool(z[f"g{g}_terminal"][k]) and winner == z[f"g{g}_winner"][k], (g, k)
+    # error behaviour: occupied / out-of-range raise ValueError in the reference
+    s = np.zeros(d["numel"], np.float32)
+    s, _ = oracle.next_state(game, n, s, 0, 1)
+    for a, key in ((0, "err_occupied"), (-1, "err_neg"), (10 ** 6, "err_big")):
+        raised = False
+        try:
+            oracle.next_state(game, n, s, a, -1)
+        except ValueError:
+            raised = True
+        assert raised == bool(z[key]), key
+
+
+def _table(c):
+    return {c["eval_in"][i].astype(np.float32).tobytes(): (c["eval_logits"][i], float(c["eval_value"][i]))
+            for i in range(len(c["eval_in"]))}
+
+
+SEARCH = load_cases("search.npz")
+
+
+@pytest.mark.parametrize("tag", sorted(SEARCH))
+def test_search_kat(oracle, tag):
+    c = SEARCH[tag]
+    game, n = game_of(tag)
+    ev = oracle.table_eval(_table(c))  # KeyError here <=> the oracle built a different NN input
+    noise = c["noise"] if c["noise"].size else None
+    D = c["trace"].shape[1]
+    r = oracle.search(game, n, c["root_state"].astype(np.float32), int(c["root_player"]),
+                      c["history"].astype(np.float32), int(c["num_sim"]), ev, noise=noise, trace_stride=D)
+    assert np.array_equal(r["visits"], c["visits"])           # bit-exact decisions
+    assert np.array_equal(r["trace"], c["trace"])             # every simulation took the same path
+    assert np.array_equal(r["pi"], c["pi"])                   # visits/sum: exact
+    np.testing.assert_allclose(r["root_prior"], c["root_prior"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(r["child_q"], c["child_q"], rtol=1e-5, atol=1e-9)
+    lp = r["leaf_prior"][r["leaf_prior"].sum(1) > 0]
+    np.testing.assert_allclose(lp, c["priors"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", sorted(SEARCH))
+def test_search_kat_reference_priors(oracle, tag):
+    """Same, with the reference's own final priors fed back in: then Q is bit-exact too, which pins
+    the tree arithmetic (PUCT dtype chain, f64 running mean, sign-aware backup) on its own."""
+    c = SEARCH[tag]
+    game, n = game_of(tag)
+    ev = oracle.table_eval(_table(c))
+    noise = c["noise"] if c["noise"].size else None
+    r = oracle.search(game, n, c["root_state"].astype(np.float32), int(c["root_player"]),
+                      c["history"].astype(np.float32), int(c["num_sim"]), ev, noise=noise,
+                      prior_override=c["priors"], trace_stride=c["trace"].shape[1])
+    assert np.array_equal(r["visits"], c["visits"])
+    assert np.array_equal(r["trace"], c["trace"])
+    assert np.array_equal(r["child_q"], c["child_q"])
+    assert np.array_equal(r["root_prior"], c["root_prior"])
+
+
+SELFPLAY = load_cases("selfplay.npz")
+
+
+@pytest.mark.parametrize("tag", sorted(SELFPLAY))
+def test_selfplay_kat(oracle, tag):
+    c = SELFPLAY[tag]
+    game, n = game_of(tag)
+    ev = oracle.table_eval(_table(c))
+    r = oracle.self_play(game, n, int(c["num_sim"]), float(c["tao"]), c["expo"], ev, noise=c["noise"])
+    T = int(c["plies"])
+    assert r["plies"] == T
+    assert np.array_equal(r["actions"], c["actions"])
+    # the reference puts the last position first (training/self_play.py:120-139)
+    assert np.array_equal(r["nn_states"][::-1].astype(np.int8), c["put_states"])
+    assert np.array_equal(r["pis"][::-1], c["put_pis"])
+    assert np.array_equal(r["z"][::-1], c["put_z"])
+    assert tuple(c["state_shape"][:1]) == (1,) and tuple(c["pi_shape"]) == (1, r["pis"].shape[1])
+
+
+def test_expf_logf_accuracy(oracle):
+    import math
+
+    xs = np.linspace(-80, 0, 4001, dtype=np.float32)
+    lg = np.zeros(2, np.float32)
+    for x in xs[::40]:
+        # softmax of [0, x] exercises az_expf(x)
+        p = oracle.get_prior(0, 3, np.array([0, x] + [-1e9] * 7, np.float32), np.ones(9, np.float32))
+        want = math.exp(float(x)) / (1 + math.exp(float(x)))
+        assert abs(p[1] - want) <= 3e-7 * want + 1e-38
+    for x, y in [(0.5, 2.0), (0.02, 10.0), (0.9, 1.0 / 0.7), (1.0, 3.0), (0.0, 2.0), (0.3, 1.0)]:
+        assert abs(oracle.powf(x, y) - x ** y) <= 2e-5 * (x ** y) + 1e-30
