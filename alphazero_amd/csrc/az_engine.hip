@@ -1,0 +1,874 @@
+// az_engine.hip -- many-tree MCTS self-play engine for MI355X (gfx950, wave64).  C ABI: include/az_engine.h
+//
+// Data layout in HBM (all owned by the engine, allocated once in az_create):
+//   per tree g (one per game slot), a bump-allocated pool of CHILD RECORDS ("edges"), struct of arrays,
+//   tree-major so that the children of one node are one contiguous, coalesced run:
+//     edgeP   f32  [G][E]   prior of the child (the parent's prior[0, action])
+//     edgeN   i32  [G][E]   child.visits
+//     edgeQ   f64  [G][E]   child.value (running mean, the child's own point of view)
+//     edgeAct u16  [G][E]   action | same_player << 15  (child.player == parent.player)
+//     edgeKid i32  [G][E]   index of the child's own node record once expanded, else -1
+//   node    int2 [G][S+1]   {first edge, number of edges} of every EXPANDED node (node 0 = root)
+//   treeCnt int2 [G]        {nodes used, edges used};  rootN i32 [G], rootQ f64 [G]
+//   per simulation:  path i32 [G][D] (edge followed at each level), leaf int4 [G]
+//   {depth, kind, value bits, player}, leafState u32 [G][SW]
+//   per game: the whole trajectory as bitboards, traj u32 [G][PMAX+1][SW] (entry t = position after
+//   t plies; the 8-deep history window of the reference is just entries t-7..t), trajPlayer i8,
+//   trajVisits u16 [G][PMAX][A] (pi is kept as integer visit counts and divided on emission).
+//
+// Children are never materialised as boards (the reference clones A boards per expansion,
+// core/MCTS_alphazero.py:51-56): a descent replays its moves on a bitboard held in LDS.
+//
+// Execution model: ONE WAVEFRONT PER TREE (blockDim = 64, grid = slots).  Lanes stride over the
+// children of a node; argmax / sums are DPP/shuffle butterflies; the board and the 8-state history
+// ring live in LDS.  Every kernel is a single pass over independent trees: no inter-workgroup
+// communication, no atomics except the error flag.
+//
+// Floating point follows the reference's dtype chain exactly (see k_select_gather) and is compiled
+// with -ffp-contract=off and correctly rounded f32 divide/sqrt; expf/logf are fmaf polynomials so
+// that the CPU oracle used by the tests reproduces them bit for bit.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/az_engine.h"
+#include "az_games.cuh"
+
+namespace az {
+
+enum : int { KIND_EVAL = 0, KIND_TERMINAL = 1 };
+enum : int { ERR_EDGE_CAP = 1, ERR_NODE_CAP = 2, ERR_DEPTH_CAP = 4, ERR_ILLEGAL = 8, ERR_NO_ROOT = 16 };
+
+struct View {  // kernel argument: raw device pointers + sizes
+  int G, E, NC, D;
+  float c_puct, epsilon;
+  float *edgeP;
+  int32_t *edgeN;
+  double *edgeQ;
+  uint16_t *edgeAct;
+  int32_t *edgeKid;
+  int2 *node;
+  int2 *treeCnt;
+  int32_t *rootN;
+  double *rootQ;
+  int32_t *path;
+  int4 *leaf;
+  uint32_t *leafState;
+  uint32_t *traj;
+  int8_t *trajPlayer;
+  uint16_t *trajVisits;
+  int32_t *ply;
+  int32_t *player;
+  uint8_t *active;
+  float *result;
+  unsigned long long *stat;  // [G][6]
+  int32_t *err;
+};
+
+// ------------------------------------------------------------------------- math helpers -------
+__device__ __forceinline__ float az_expf(float x) {  // x <= 0; same fmaf chain as oracle/az_oracle.c
+  if (x < -87.0f) return 0.0f;
+  const float n = rintf(x * 1.44269504088896341f);
+  float r = fmaf(-n, 0.693145751953125f, x);
+  r = fmaf(-n, 1.428606765330187045e-06f, r);
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  p = fmaf(p * r, r, r);
+  p = p + 1.0f;
+  return p * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
+
+__device__ __forceinline__ float az_logf(float x) {  // x > 0, normal
+  uint32_t u = __float_as_uint(x);
+  int e = (int)(u >> 23) - 127;
+  float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+  if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+  const float s = (m - 1.0f) / (m + 1.0f);
+  const float z = s * s;
+  float p = 0.0909090936183929f;
+  p = fmaf(p, z, 0.1111111119389534f);
+  p = fmaf(p, z, 0.1428571492433548f);
+  p = fmaf(p, z, 0.2f);
+  p = fmaf(p, z, 0.3333333432674408f);
+  p = fmaf(p * z, s, s);
+  const float fe = (float)e;
+  return fmaf(fe, 0.693145751953125f, fmaf(fe, 1.428606765330187045e-06f, 2.0f * p));
+}
+
+__device__ __forceinline__ float az_powf(float x, float y) {  // torch.pow(pi, 1/tao), pi in [0,1]
+  if (y == 1.0f) return x;
+  if (x <= 0.0f) return 0.0f;
+  float t = y * az_logf(x);
+  if (t > 0.0f) t = 0.0f;
+  return az_expf(t);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {  // xor butterfly, fixed order
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <typename T> __device__ __forceinline__ T cvt_out(float v);
+template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+struct bf16_t { uint16_t u; };
+struct f16_t { uint16_t u; };
+// the batch only ever holds -1, 0, +1: exact in both 16-bit formats
+template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float v) { return bf16_t{(uint16_t)(__float_as_uint(v) >> 16)}; }
+template <> __device__ __forceinline__ f16_t cvt_out<f16_t>(float v) {
+  return f16_t{(uint16_t)(v == 0.0f ? 0u : (v > 0.0f ? 0x3C00u : 0xBC00u))};
+}
+template <typename T> __device__ __forceinline__ float cvt_in(T v);
+template <> __device__ __forceinline__ float cvt_in<float>(float v) { return v; }
+template <> __device__ __forceinline__ float cvt_in<bf16_t>(bf16_t v) { return __uint_as_float((uint32_t)v.u << 16); }
+template <> __device__ __forceinline__ float cvt_in<f16_t>(f16_t v) {
+  return v.u == 0 ? 0.0f : ((v.u & 0x8000u) ? -1.0f : 1.0f);
+}
+
+// NN input of the position whose 8-state history ring is `hist` (oldest at index head):
+// core/MCTS_alphazero.py:202-209 + utils/history_manager.py:41-47 + games/base.py:116-121.
+template <class GT, typename OutT>
+__device__ __forceinline__ void write_planes(const uint32_t (*hist)[GT::SW], int head, int player, OutT *out, int lane) {
+  constexpr int NIN = GT::CIN * GT::HW;
+  for (int idx = lane; idx < NIN; idx += 64) {
+    const int c = idx / GT::HW, cell = idx % GT::HW;
+    float v;
+    if (c == GT::CIN - 1) v = (float)player;
+    else v = GT::plane(hist[(head + c / GT::CS) & 7], c % GT::CS, cell);
+    out[idx] = cvt_out<OutT>(v);
+  }
+}
+
+// load the ring of the position at ply `ply` of game g: entries ply-7..ply, zeros before the start
+template <class GT>
+__device__ __forceinline__ void load_ring(const uint32_t *tb, int ply, uint32_t (*hist)[GT::SW], int lane) {
+  for (int i = lane; i < 8 * GT::SW; i += 64) {
+    const int k = i / GT::SW, w = i % GT::SW, t = ply - 7 + k;
+    hist[k][w] = t >= 0 ? tb[(size_t)t * GT::SW + w] : 0u;
+  }
+}
+
+// ------------------------------------------------------------------------- select + gather ----
+// One simulation's descent.  MCTS.search :145-160; MCTSNode.select :59-78 with the dtype chain
+//   puct = f32(q64) + ((f32(c_puct) * P) * f32(sqrt64(N_parent))) / f32(n + 1),   strict '>' (lowest
+// action wins ties), q64 = +child.value if the child has the parent's player else -child.value.
+template <class GT, typename OutT>
+__global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if (!v.active[g]) return;
+  __shared__ uint32_t hist[8][GT::SW];
+  __shared__ uint32_t cur[GT::SW];
+  const int ply = v.ply[g];
+  int pl = v.player[g];
+  const uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
+  load_ring<GT>(tb, ply, hist, lane);
+  if (lane < GT::SW) cur[lane] = tb[(size_t)ply * GT::SW + lane];
+  __syncthreads();
+
+  const size_t eb = (size_t)g * v.E;
+  const int2 cnt = v.treeCnt[g];
+  int head = 0, depth = 0, kind = KIND_EVAL, node = 0;
+  int nParent = v.rootN[g];
+  float tval = 0.0f;
+  unsigned long long scanned = 0;
+  if (cnt.x > 0) {
+    for (;;) {
+      if (depth >= v.D) { if (lane == 0) atomicOr(v.err, ERR_DEPTH_CAP); return; }
+      const int2 nd = v.node[(size_t)g * v.NC + node];
+      const float sqrtN = (float)sqrt((double)nParent);
+      float best = -INFINITY;
+      int bestIdx = 0x7fffffff;
+      for (int i = lane; i < nd.y; i += 64) {
+        const size_t e = eb + nd.x + i;
+        const float P = v.edgeP[e];
+        const int n = v.edgeN[e];
+        const double q = v.edgeQ[e];
+        const unsigned act = v.edgeAct[e];
+        const double qs = (act & 0x8000u) ? q : -q;
+        const float u = ((v.c_puct * P) * sqrtN) / (float)(n + 1);
+        const float sc = (float)qs + u;
+        if (sc > best) { best = sc; bestIdx = i; }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bestIdx, off, 64);
+        if (ob > best || (ob == best && oi < bestIdx)) { best = ob; bestIdx = oi; }
+      }
+      bestIdx = uni(bestIdx);
+      scanned += (unsigned)nd.y;
+      if (bestIdx >= nd.y) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
+      const int el = nd.x + bestIdx;
+      const unsigned act = uni((int)v.edgeAct[eb + el]);
+      const int a = (int)(act & 0x7fffu);
+      const int kid = uni(v.edgeKid[eb + el]);
+      const int nEdge = uni(v.edgeN[eb + el]);
+      if (lane == 0) v.path[(size_t)g * v.D + depth] = el;
+      ++depth;
+      const int mover = pl;
+      pl = GT::apply(cur, a, mover, lane);
+      if (lane < GT::SW) hist[head][lane] = cur[lane];
+      head = (head + 1) & 7;
+      __syncthreads();
+      if (kid >= 0) { node = kid; nParent = nEdge; continue; }
+      const int term = uni(GT::terminal(cur, a, mover, ply + depth, lane));
+      if (term != T_NONE) { kind = KIND_TERMINAL; tval = terminal_value(term, pl); }
+      break;
+    }
+  }
+  if (lane == 0) {
+    v.leaf[g] = make_int4(depth, kind, (int)__float_as_uint(tval), pl);
+    unsigned long long *st = v.stat + (size_t)g * 6;
+    st[0] += 1; st[1] += (unsigned)depth; st[2] += scanned;
+    st[3] += (kind == KIND_EVAL); st[4] += (kind == KIND_TERMINAL);
+  }
+  if (kind == KIND_EVAL) {
+    if (lane < GT::SW) v.leafState[(size_t)g * GT::SW + lane] = cur[lane];
+    write_planes<GT, OutT>(hist, head, pl, nn_input + (size_t)g * (GT::CIN * GT::HW), lane);
+  }
+}
+
+// ------------------------------------------------------------------------- expand + backup ----
+// MCTS._get_prior :180-192, MCTSNode.expand :43-57, MCTSNode.update :80-88, MCTS._bacaward :194-200.
+template <class GT>
+__global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logits, const float *values,
+                                                      const float *noise) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if (!v.active[g]) return;
+  __shared__ uint32_t st[GT::SW];
+  const int4 lf = v.leaf[g];
+  const int depth = lf.x, kind = lf.y;
+  const size_t eb = (size_t)g * v.E;
+  const int32_t *path = v.path + (size_t)g * v.D;
+  double val;
+  if (kind == KIND_EVAL) {
+    if (lane < GT::SW) st[lane] = v.leafState[(size_t)g * GT::SW + lane];
+    __syncthreads();
+    constexpr int A = GT::A, NI = (A + 63) / 64;
+    float p[NI];
+    bool lg[NI];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int a = lane + 64 * i;
+      p[i] = a < A ? logits[(size_t)g * A + a] : -INFINITY;
+      mx = fmaxf(mx, p[i]);
+    }
+    mx = wave_max(mx);
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int a = lane + 64 * i;
+      p[i] = a < A ? az_expf(p[i] - mx) : 0.0f;
+      acc = acc + p[i];
+    }
+    const float inv = 1.0f / wave_sum(acc);
+    const bool mix = (noise != nullptr) && depth == 0;  // node is root_node and use_Dirichlet
+    const float keep = (float)(1.0 - (double)v.epsilon);
+    acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int a = lane + 64 * i;
+      float x = p[i] * inv;
+      if (mix && a < A) x = keep * x + v.epsilon * noise[(size_t)g * A + a];
+      lg[i] = a < A && GT::legal(st, a);
+      x = x * (lg[i] ? 1.0f : 0.0f);
+      p[i] = x;
+      acc = acc + x;
+    }
+    const float tot = wave_sum(acc);
+    const int2 cnt = v.treeCnt[g];
+    int nLegal = 0;
+    unsigned long long bal[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { bal[i] = __ballot(lg[i]); nLegal += __popcll(bal[i]); }
+    if (cnt.y + nLegal > v.E) { if (lane == 0) atomicOr(v.err, ERR_EDGE_CAP); return; }
+    if (cnt.x >= v.NC) { if (lane == 0) atomicOr(v.err, ERR_NODE_CAP); return; }
+    int off = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int a = lane + 64 * i;
+      if (lg[i]) {
+        const int pos = off + __popcll(bal[i] & ((1ull << lane) - 1ull));
+        const size_t e = eb + cnt.y + pos;
+        v.edgeP[e] = p[i] / tot;
+        v.edgeN[e] = 0;
+        v.edgeQ[e] = 0.0;
+        v.edgeAct[e] = (uint16_t)(a | (GT::same_player(st, a) ? 0x8000 : 0));
+        v.edgeKid[e] = -1;
+      }
+      off += __popcll(bal[i]);
+    }
+    if (lane == 0) {
+      v.node[(size_t)g * v.NC + cnt.x] = make_int2(cnt.y, nLegal);
+      v.treeCnt[g] = make_int2(cnt.x + 1, cnt.y + nLegal);
+      if (depth > 0) v.edgeKid[eb + path[depth - 1]] = cnt.x;
+      v.stat[(size_t)g * 6 + 5] += (unsigned)nLegal;
+    }
+    val = (double)values[g];  // value.item()
+  } else {
+    val = (double)__uint_as_float((uint32_t)lf.z);
+  }
+  // backup: lane j owns path edge depth-1-j; the value it receives has been negated once for every
+  // edge BELOW it whose child is the other player's node.
+  for (int base = 0; base < depth; base += 64) {
+    const int j = base + lane;
+    bool flip = false;
+    size_t e = 0;
+    if (j < depth) {
+      e = eb + path[depth - 1 - j];
+      flip = (v.edgeAct[e] & 0x8000u) == 0u;
+    }
+    const unsigned long long fm = __ballot(flip);
+    if (j < depth) {
+      const int below = __popcll(fm & ((1ull << lane) - 1ull));
+      const double x = (below & 1) ? -val : val;
+      const int n = v.edgeN[e] + 1;
+      const double q = v.edgeQ[e];
+      v.edgeN[e] = n;
+      v.edgeQ[e] = q + (x - q) / (double)n;
+    }
+    if (__popcll(fm) & 1) val = -val;
+  }
+  if (lane == 0) {
+    const int n = v.rootN[g] + 1;
+    const double q = v.rootQ[g];
+    v.rootN[g] = n;
+    v.rootQ[g] = q + (val - q) / (double)n;
+  }
+}
+
+// ------------------------------------------------------------------------- root policy --------
+template <class GT>
+__global__ __launch_bounds__(64) void k_root_policy(View v, float *pi, int32_t *visits, double *childQ, float *rootPrior) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  constexpr int A = GT::A;
+  __shared__ int edgeOf[A];  // action -> root edge + 1, 0 where the action is illegal
+  for (int a = lane; a < A; a += 64) edgeOf[a] = 0;
+  __syncthreads();
+  const bool have = v.active[g] && v.treeCnt[g].x > 0;
+  const size_t eb = (size_t)g * v.E;
+  float tot = 1.0f;
+  if (have) {
+    const int2 nd = v.node[(size_t)g * v.NC];
+    int s = 0;
+    for (int i = lane; i < nd.y; i += 64) {
+      s += v.edgeN[eb + nd.x + i];
+      edgeOf[v.edgeAct[eb + nd.x + i] & 0x7fffu] = nd.x + i + 1;
+    }
+    tot = (float)wave_sum_i(s);
+  }
+  __syncthreads();
+  for (int a = lane; a < A; a += 64) {
+    const int k = edgeOf[a];
+    const size_t e = eb + (k > 0 ? k - 1 : 0);
+    const size_t o = (size_t)g * A + a;
+    if (pi) pi[o] = k ? (float)v.edgeN[e] / tot : 0.0f;
+    if (visits) visits[o] = k ? v.edgeN[e] : 0;
+    if (childQ) childQ[o] = k ? v.edgeQ[e] : 0.0;
+    if (rootPrior) rootPrior[o] = k ? v.edgeP[e] : 0.0f;
+  }
+}
+
+template <class GT>
+__global__ __launch_bounds__(64) void k_root_nn_state(View v, float *out) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if (!v.active[g]) return;
+  __shared__ uint32_t hist[8][GT::SW];
+  const int ply = v.ply[g];
+  load_ring<GT>(v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW, ply, hist, lane);
+  __syncthreads();
+  write_planes<GT, float>(hist, 0, v.player[g], out + (size_t)g * (GT::CIN * GT::HW), lane);
+}
+
+// ------------------------------------------------------------------------- play a move --------
+// training/self_play.py:73-83, games/base.py:22-33, and the result flip of :86-89.
+template <class GT>
+__global__ __launch_bounds__(64) void k_play_moves(View v, const float *invTao, const float *expo, const int32_t *forced,
+                                                   int32_t *actions, uint8_t *done) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  constexpr int A = GT::A;
+  if (!v.active[g]) {
+    if (lane == 0) { if (actions) actions[g] = -1; if (done) done[g] = 0; }
+    return;
+  }
+  __shared__ uint32_t cur[GT::SW];
+  __shared__ uint16_t vis[A];
+  for (int a = lane; a < A; a += 64) vis[a] = 0;
+  const int ply = v.ply[g], player = v.player[g];
+  uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
+  if (lane < GT::SW) cur[lane] = tb[(size_t)ply * GT::SW + lane];
+  __syncthreads();
+  if (v.treeCnt[g].x == 0 || ply >= GT::PMAX) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
+  const int2 nd = v.node[(size_t)g * v.NC];
+  const size_t eb = (size_t)g * v.E;
+  int s = 0;
+  for (int i = lane; i < nd.y; i += 64) s += v.edgeN[eb + nd.x + i];
+  const float tot = (float)wave_sum_i(s);
+  const float it = invTao[g];
+  float best = -INFINITY;
+  int bestA = 0x7fffffff;
+  for (int i = lane; i < nd.y; i += 64) {
+    const size_t e = eb + nd.x + i;
+    const int a = v.edgeAct[e] & 0x7fffu, n = v.edgeN[e];
+    vis[a] = (uint16_t)n;
+    const float pi = (float)n / tot;
+    const float q = az_powf(pi, it) / expo[(size_t)g * A + a];
+    if (q > best) { best = q; bestA = a; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 64);
+    const int oa = __shfl_xor(bestA, off, 64);
+    if (ob > best || (ob == best && oa < bestA)) { best = ob; bestA = oa; }
+  }
+  int a = uni(bestA);
+  if (forced && forced[g] >= 0) a = uni(forced[g]);
+  __syncthreads();
+  if (a < 0 || a >= A || !GT::legal(cur, a)) { if (lane == 0) atomicOr(v.err, ERR_ILLEGAL); return; }
+  uint16_t *tv = v.trajVisits + ((size_t)g * GT::PMAX + ply) * A;
+  for (int k = lane; k < A; k += 64) tv[k] = vis[k];
+  const int np = GT::apply(cur, a, player, lane);
+  if (lane < GT::SW) tb[(size_t)(ply + 1) * GT::SW + lane] = cur[lane];
+  const int term = uni(GT::terminal(cur, a, player, ply + 1, lane));
+  if (lane == 0) {
+    v.trajPlayer[(size_t)g * (GT::PMAX + 1) + ply] = (int8_t)player;
+    v.ply[g] = ply + 1;
+    v.player[g] = np;
+    if (actions) actions[g] = a;
+    if (done) done[g] = term != T_NONE;
+    if (term != T_NONE) {
+      v.active[g] = 0;
+      float r = terminal_value(term, np);  // game.evaluation(): the player to move's view
+      v.result[g] = (np == player) ? r : -r;  // ... flipped to the last mover's (self_play.py:89)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- emit samples -------
+// training/self_play.py:110-139: sample j of a finished game is ply t = T-1-j; its z is the result if
+// that ply's mover is the last mover, else its negation (the cumulative flips of :131 telescope).
+template <class GT>
+__global__ __launch_bounds__(64) void k_emit_samples(View v, const int32_t *slots, const int32_t *offsets, float *states,
+                                                     float *pis, float *zs) {
+  const int g = slots[blockIdx.x], j = blockIdx.y, lane = threadIdx.x;
+  constexpr int A = GT::A;
+  if (g < 0 || g >= v.G) return;
+  const int T = v.ply[g];
+  if (j >= T) return;
+  const int t = T - 1 - j;
+  const size_t row = (size_t)offsets[blockIdx.x] + j;
+  __shared__ uint32_t hist[8][GT::SW];
+  load_ring<GT>(v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW, t, hist, lane);
+  __syncthreads();
+  const int8_t *tp = v.trajPlayer + (size_t)g * (GT::PMAX + 1);
+  const int pl = tp[t];
+  write_planes<GT, float>(hist, 0, pl, states + row * (GT::CIN * GT::HW), lane);
+  const uint16_t *tv = v.trajVisits + ((size_t)g * GT::PMAX + t) * A;
+  int s = 0;
+  for (int a = lane; a < A; a += 64) s += tv[a];
+  const float tot = (float)wave_sum_i(s);
+  for (int a = lane; a < A; a += 64) pis[row * A + a] = (float)tv[a] / tot;
+  if (lane == 0) {
+    const float r = v.result[g];
+    zs[row] = (pl == tp[T - 1]) ? r : -r;
+  }
+}
+
+// ------------------------------------------------------------------------- small kernels ------
+template <class GT>
+__global__ void k_reset_games(View v, const uint8_t *mask) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= v.G || (mask && !mask[g])) return;
+  uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
+  for (int w = 0; w < GT::SW; ++w) tb[w] = 0u;
+  v.ply[g] = 0;
+  v.player[g] = 1;
+  v.active[g] = 1;
+  v.result[g] = 0.0f;
+  v.treeCnt[g] = make_int2(0, 0);
+  v.rootN[g] = 0;
+  v.rootQ[g] = 0.0;
+}
+
+__global__ void k_begin_search(View v) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= v.G) return;
+  v.treeCnt[g] = make_int2(0, 0);
+  v.rootN[g] = 0;
+  v.rootQ[g] = 0.0;
+}
+
+__global__ void k_game_info(View v, int32_t *plies, int32_t *player, uint8_t *active, float *result) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= v.G) return;
+  if (plies) plies[g] = v.ply[g];
+  if (player) player[g] = v.player[g];
+  if (active) active[g] = v.active[g];
+  if (result) result[g] = v.result[g];
+}
+
+// Synthetic evaluator, identical to az_oracle_eval_hash in oracle/az_oracle.c.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+template <typename InT>
+__global__ __launch_bounds__(64) void k_eval_hash(int nin, int A, const InT *nn_input, float scale, float *logits, float *values) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const InT *x = nn_input + (size_t)g * nin;
+  uint32_t h = 0;
+  for (int i = lane; i < nin; i += 64) {
+    const uint32_t code = (uint32_t)((int)cvt_in<InT>(x[i]) + 1);
+    h += mix32((uint32_t)i * 2654435761u + code * 40503u + 12345u);
+  }
+  h = (uint32_t)wave_sum_i((int)h);
+  for (int a = lane; a < A; a += 64) {
+    const uint32_t r = mix32(h + (uint32_t)a * 0x9E3779B9u + 1u);
+    logits[(size_t)g * A + a] = scale * ((float)((r >> 8) & 0xFFFFu) * (1.0f / 65536.0f) - 0.5f);
+  }
+  if (lane == 0) {
+    const uint32_t r = mix32(h ^ 0x00ABCDEFu);
+    values[g] = (float)((r >> 8) & 0xFFFFu) * (1.0f / 32768.0f) - 1.0f;
+  }
+}
+
+}  // namespace az
+
+// =========================================================================== host side =========
+using namespace az;
+
+struct az_engine {
+  az_config cfg;
+  az_dims dims;
+  View v;
+  std::vector<void *> allocs;
+  std::string err;
+  int nin;
+};
+
+static std::string g_create_err;
+
+#define AZ_HIP(call)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (call);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      e->err = std::string(#call) + ": " + hipGetErrorString(_e);                           \
+      return AZ_EHIP;                                                                       \
+    }                                                                                       \
+  } while (0)
+
+// dispatch on the game: body sees `GT`
+#define AZ_DISPATCH(e, BODY)                                                                \
+  do {                                                                                      \
+    switch ((e)->cfg.game) {                                                                \
+      case AZ_GAME_TICTACTOE: { using GT = az::TicTacToe; BODY; } break;                    \
+      case AZ_GAME_DAB: { using GT = az::Dab; BODY; } break;                                \
+      default:                                                                              \
+        if ((e)->cfg.board_size == 9) { using GT = az::Gomoku<9>; BODY; }                   \
+        else { using GT = az::Gomoku<15>; BODY; }                                           \
+        break;                                                                              \
+    }                                                                                       \
+  } while (0)
+
+template <class GT>
+static void fill_dims(az_dims &d) {
+  d.n_action = GT::A; d.state_channels = GT::CS; d.height = GT::H; d.width = GT::WD;
+  d.nn_channels = GT::CIN; d.max_plies = GT::PMAX; d.state_words = GT::SW;
+}
+
+static int launch_check(az_engine *e, const char *what) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    e->err = std::string(what) + ": " + hipGetErrorString(err);
+    return AZ_EHIP;
+  }
+  return AZ_OK;
+}
+
+extern "C" {
+
+const char *az_last_error(const az_engine *e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int az_create(const az_config *cfg, az_engine **out) {
+  if (!cfg || !out) { g_create_err = "null argument"; return AZ_EINVAL; }
+  *out = nullptr;
+  if (cfg->game < AZ_GAME_TICTACTOE || cfg->game > AZ_GAME_GOMOKU) { g_create_err = "unknown game"; return AZ_EINVAL; }
+  if (cfg->game == AZ_GAME_GOMOKU && cfg->board_size != 9 && cfg->board_size != 15) {
+    g_create_err = "gomoku board_size must be 9 or 15"; return AZ_EINVAL;
+  }
+  if (cfg->n_slots < 1 || cfg->max_sims < 1 || cfg->max_sims > 65535) {
+    g_create_err = "n_slots >= 1 and 1 <= max_sims <= 65535 required"; return AZ_EINVAL;
+  }
+  if (cfg->nn_dtype < AZ_NN_F32 || cfg->nn_dtype > AZ_NN_F16) { g_create_err = "bad nn_dtype"; return AZ_EINVAL; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev) {
+    g_create_err = "no usable HIP device (this library has no CPU path)"; return AZ_EHIP;
+  }
+  az_engine *e = new az_engine();
+  e->cfg = *cfg;
+  memset(&e->dims, 0, sizeof(e->dims));
+  AZ_DISPATCH(e, fill_dims<GT>(e->dims));
+  az_dims &d = e->dims;
+  const int A = d.n_action;
+  d.n_slots = cfg->n_slots;
+  d.node_cap = cfg->max_sims + 1;
+  const long long worst = (long long)cfg->max_sims * A;
+  d.edge_cap = (int)(cfg->edge_cap > 0 ? (long long)cfg->edge_cap : worst);
+  if (d.edge_cap < A) d.edge_cap = A;
+  d.depth_cap = (cfg->max_sims < d.max_plies ? cfg->max_sims : d.max_plies) + 1;
+  e->nin = d.nn_channels * d.height * d.width;
+  if ((hipSetDevice(cfg->device)) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete e; return AZ_EHIP; }
+
+  View &v = e->v;
+  memset(&v, 0, sizeof(v));
+  v.G = d.n_slots; v.E = d.edge_cap; v.NC = d.node_cap; v.D = d.depth_cap;
+  v.c_puct = cfg->c_puct; v.epsilon = cfg->epsilon;
+  const size_t G = (size_t)d.n_slots, E = (size_t)d.edge_cap;
+  int64_t total = 0;
+  bool ok = true;
+  auto alloc = [&](size_t bytes) -> void * {
+    void *p = nullptr;
+    if (!ok) return nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { ok = false; return nullptr; }
+    e->allocs.push_back(p);
+    total += (int64_t)bytes;
+    return p;
+  };
+  v.edgeP = (float *)alloc(G * E * sizeof(float));
+  v.edgeN = (int32_t *)alloc(G * E * sizeof(int32_t));
+  v.edgeQ = (double *)alloc(G * E * sizeof(double));
+  v.edgeAct = (uint16_t *)alloc(G * E * sizeof(uint16_t));
+  v.edgeKid = (int32_t *)alloc(G * E * sizeof(int32_t));
+  v.node = (int2 *)alloc(G * (size_t)d.node_cap * sizeof(int2));
+  v.treeCnt = (int2 *)alloc(G * sizeof(int2));
+  v.rootN = (int32_t *)alloc(G * sizeof(int32_t));
+  v.rootQ = (double *)alloc(G * sizeof(double));
+  v.path = (int32_t *)alloc(G * (size_t)d.depth_cap * sizeof(int32_t));
+  v.leaf = (int4 *)alloc(G * sizeof(int4));
+  v.leafState = (uint32_t *)alloc(G * (size_t)d.state_words * sizeof(uint32_t));
+  v.traj = (uint32_t *)alloc(G * (size_t)(d.max_plies + 1) * d.state_words * sizeof(uint32_t));
+  v.trajPlayer = (int8_t *)alloc(G * (size_t)(d.max_plies + 1));
+  v.trajVisits = (uint16_t *)alloc(G * (size_t)d.max_plies * A * sizeof(uint16_t));
+  v.ply = (int32_t *)alloc(G * sizeof(int32_t));
+  v.player = (int32_t *)alloc(G * sizeof(int32_t));
+  v.active = (uint8_t *)alloc(G);
+  v.result = (float *)alloc(G * sizeof(float));
+  v.stat = (unsigned long long *)alloc(G * 6 * sizeof(unsigned long long));
+  v.err = (int32_t *)alloc(sizeof(int32_t));
+  if (!ok) {
+    g_create_err = "hipMalloc failed (engine needs " + std::to_string(total >> 20) + "+ MiB)";
+    for (void *p : e->allocs) (void)hipFree(p);
+    delete e;
+    return AZ_ENOMEM;
+  }
+  d.device_bytes = total;
+  // small state starts defined; the big pools need no clearing (bump allocated, written before read)
+  if (hipMemset(v.stat, 0, G * 6 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(v.err, 0, sizeof(int32_t)) != hipSuccess || hipMemset(v.active, 0, G) != hipSuccess ||
+      hipMemset(v.ply, 0, G * sizeof(int32_t)) != hipSuccess || hipMemset(v.leaf, 0, G * sizeof(int4)) != hipSuccess ||
+      hipMemset(v.trajPlayer, 0, G * (size_t)(d.max_plies + 1)) != hipSuccess) {
+    g_create_err = "hipMemset failed";
+    for (void *p : e->allocs) (void)hipFree(p);
+    delete e;
+    return AZ_EHIP;
+  }
+  *out = e;
+  int rc = az_reset_games(e, nullptr, nullptr);
+  if (rc == AZ_OK && hipDeviceSynchronize() != hipSuccess) rc = AZ_EHIP;
+  if (rc != AZ_OK) { g_create_err = e->err; az_destroy(e); *out = nullptr; }
+  return rc;
+}
+
+int az_destroy(az_engine *e) {
+  if (!e) return AZ_EINVAL;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (void *p : e->allocs) (void)hipFree(p);
+  delete e;
+  return AZ_OK;
+}
+
+int az_get_dims(const az_engine *e, az_dims *out) {
+  if (!e || !out) return AZ_EINVAL;
+  *out = e->dims;
+  return AZ_OK;
+}
+
+int az_check(az_engine *e, void *stream) {
+  if (!e) return AZ_EINVAL;
+  int32_t flag = 0;
+  AZ_HIP(hipMemcpyAsync(&flag, e->v.err, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  AZ_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (flag) {
+    e->err = "device error flags:";
+    if (flag & ERR_EDGE_CAP) e->err += " edge pool exhausted (raise edge_cap/max_sims)";
+    if (flag & ERR_NODE_CAP) e->err += " node pool exhausted (more simulations than max_sims)";
+    if (flag & ERR_DEPTH_CAP) e->err += " path deeper than depth_cap";
+    if (flag & ERR_ILLEGAL) e->err += " illegal move";
+    if (flag & ERR_NO_ROOT) e->err += " root not expanded / no child to select";
+    return AZ_EDEVICE;
+  }
+  return AZ_OK;
+}
+
+int az_reset_games(az_engine *e, const uint8_t *mask_dev, void *stream) {
+  if (!e) return AZ_EINVAL;
+  const int G = e->v.G;
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_reset_games<GT>), dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->v, mask_dev));
+  return launch_check(e, "k_reset_games");
+}
+
+int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32_t root_player, void *stream) {
+  if (!e || !history_host) return AZ_EINVAL;
+  if (slot < 0 || slot >= e->v.G) { e->err = "slot out of range"; return AZ_EINVAL; }
+  if (root_player != 1 && root_player != -1) { e->err = "root_player must be +1 or -1"; return AZ_EINVAL; }
+  const az_dims &d = e->dims;
+  const int numel = d.state_channels * d.height * d.width, SW = d.state_words;
+  std::vector<uint32_t> words((size_t)8 * SW);
+  int nm[8];
+  for (int k = 0; k < 8; ++k) {
+    bool ok = false;
+    AZ_DISPATCH(e, ok = GT::encode(history_host + (size_t)k * numel, words.data() + (size_t)k * SW, &nm[k]));
+    if (!ok) { e->err = "history holds a value outside {-1,0,1} or outside the board"; return AZ_EINVAL; }
+  }
+  const int ply = nm[7];
+  if (ply >= d.max_plies) { e->err = "position has no move left"; return AZ_EINVAL; }
+  // entries older than the start of the game must be the initial (empty) state
+  for (int k = 0; k < 8; ++k) {
+    const int t = ply - 7 + k;
+    if (t < 0 && nm[k] != 0) { e->err = "history is longer than the game (non-empty state before ply 0)"; return AZ_EINVAL; }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t *tb = e->v.traj + (size_t)slot * (d.max_plies + 1) * SW;
+  for (int k = 0; k < 8; ++k) {
+    const int t = ply - 7 + k;
+    if (t < 0) continue;
+    AZ_HIP(hipMemcpyAsync(tb + (size_t)t * SW, words.data() + (size_t)k * SW, SW * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  }
+  const int32_t one_ply = ply, one_player = root_player;
+  const uint8_t act = 1;
+  const int2 zero = make_int2(0, 0);
+  AZ_HIP(hipMemcpyAsync(e->v.ply + slot, &one_ply, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  AZ_HIP(hipMemcpyAsync(e->v.player + slot, &one_player, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  AZ_HIP(hipMemcpyAsync(e->v.active + slot, &act, 1, hipMemcpyHostToDevice, s));
+  AZ_HIP(hipMemcpyAsync(e->v.treeCnt + slot, &zero, sizeof(int2), hipMemcpyHostToDevice, s));
+  AZ_HIP(hipStreamSynchronize(s));  // host staging buffers die here
+  return AZ_OK;
+}
+
+int az_begin_search(az_engine *e, void *stream) {
+  if (!e) return AZ_EINVAL;
+  const int G = e->v.G;
+  hipLaunchKernelGGL(k_begin_search, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->v);
+  return launch_check(e, "k_begin_search");
+}
+
+int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
+  if (!e || !nn_input_dev) return AZ_EINVAL;
+  const dim3 grid(e->v.G), block(64);
+  hipStream_t s = (hipStream_t)stream;
+  switch (e->cfg.nn_dtype) {
+    case AZ_NN_F32: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, float>), grid, block, 0, s, e->v, (float *)nn_input_dev)); break;
+    case AZ_NN_BF16: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, bf16_t>), grid, block, 0, s, e->v, (bf16_t *)nn_input_dev)); break;
+    default: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, f16_t>), grid, block, 0, s, e->v, (f16_t *)nn_input_dev)); break;
+  }
+  return launch_check(e, "k_select_gather");
+}
+
+int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev, void *stream) {
+  if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_backup<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, logits_dev, values_dev, noise_dev));
+  return launch_check(e, "k_expand_backup");
+}
+
+int az_root_policy(az_engine *e, float *pi_dev, int32_t *visits_dev, double *child_q_dev, float *root_prior_dev, void *stream) {
+  if (!e) return AZ_EINVAL;
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_root_policy<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, pi_dev, visits_dev, child_q_dev, root_prior_dev));
+  return launch_check(e, "k_root_policy");
+}
+
+int az_root_nn_state(az_engine *e, float *nn_state_dev, void *stream) {
+  if (!e || !nn_state_dev) return AZ_EINVAL;
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_root_nn_state<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, nn_state_dev));
+  return launch_check(e, "k_root_nn_state");
+}
+
+int az_play_moves(az_engine *e, const float *inv_tao_dev, const float *expo_dev, const int32_t *forced_actions_dev,
+                  int32_t *actions_dev, uint8_t *done_dev, void *stream) {
+  if (!e || !inv_tao_dev || !expo_dev) return AZ_EINVAL;
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_play_moves<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, inv_tao_dev, expo_dev,
+                                    forced_actions_dev, actions_dev, done_dev));
+  return launch_check(e, "k_play_moves");
+}
+
+int az_game_info(az_engine *e, int32_t *plies_dev, int32_t *player_dev, uint8_t *active_dev, float *result_dev, void *stream) {
+  if (!e) return AZ_EINVAL;
+  const int G = e->v.G;
+  hipLaunchKernelGGL(k_game_info, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->v, plies_dev, player_dev, active_dev, result_dev);
+  return launch_check(e, "k_game_info");
+}
+
+int az_emit_samples(az_engine *e, const int32_t *slots_dev, const int32_t *offsets_dev, int32_t n_games, float *states_dev,
+                    float *pis_dev, float *z_dev, void *stream) {
+  if (!e || !slots_dev || !offsets_dev || !states_dev || !pis_dev || !z_dev || n_games < 0) return AZ_EINVAL;
+  if (n_games == 0) return AZ_OK;
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_emit_samples<GT>), dim3(n_games, e->dims.max_plies), dim3(64), 0, (hipStream_t)stream, e->v,
+                                    slots_dev, offsets_dev, states_dev, pis_dev, z_dev));
+  return launch_check(e, "k_emit_samples");
+}
+
+int az_read_stats(az_engine *e, az_stats *out, void *stream) {
+  if (!e || !out) return AZ_EINVAL;
+  const size_t n = (size_t)e->v.G * 6;
+  std::vector<unsigned long long> h(n);
+  AZ_HIP(hipMemcpyAsync(h.data(), e->v.stat, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  AZ_HIP(hipStreamSynchronize((hipStream_t)stream));
+  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+  for (size_t g = 0; g < (size_t)e->v.G; ++g)
+    for (int k = 0; k < 6; ++k) acc[k] += h[g * 6 + k];
+  out->sims = acc[0]; out->sum_depth = acc[1]; out->sum_children = acc[2];
+  out->evals = acc[3]; out->terminals = acc[4]; out->expanded_edges = acc[5];
+  return AZ_OK;
+}
+
+int az_reset_stats(az_engine *e, void *stream) {
+  if (!e) return AZ_EINVAL;
+  AZ_HIP(hipMemsetAsync(e->v.stat, 0, (size_t)e->v.G * 6 * sizeof(unsigned long long), (hipStream_t)stream));
+  return AZ_OK;
+}
+
+int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *logits_dev, float *values_dev, void *stream) {
+  if (!e || !nn_input_dev || !logits_dev || !values_dev) return AZ_EINVAL;
+  const dim3 grid(e->v.G), block(64);
+  hipStream_t s = (hipStream_t)stream;
+  const int A = e->dims.n_action;
+  switch (e->cfg.nn_dtype) {
+    case AZ_NN_F32: hipLaunchKernelGGL((k_eval_hash<float>), grid, block, 0, s, e->nin, A, (const float *)nn_input_dev, scale, logits_dev, values_dev); break;
+    case AZ_NN_BF16: hipLaunchKernelGGL((k_eval_hash<bf16_t>), grid, block, 0, s, e->nin, A, (const bf16_t *)nn_input_dev, scale, logits_dev, values_dev); break;
+    default: hipLaunchKernelGGL((k_eval_hash<f16_t>), grid, block, 0, s, e->nin, A, (const f16_t *)nn_input_dev, scale, logits_dev, values_dev); break;
+  }
+  return launch_check(e, "k_eval_hash");
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// az_games.cuh -- bitboard rules of the three games, for one wavefront per position.
+//
+// A state is SW u32 words kept in LDS.  Every function is called by all 64 lanes of the wave with
+// wave-uniform arguments unless it says "per lane".  apply() contains workgroup barriers, so it is
+// only usable from kernels launched with one wave per workgroup (blockDim.x == 64).
+//
+// Reference semantics (files under the reference tree):
+//   tictactoe  examples/tictactoe/game.py:20-77
+//   dab        examples/dots_and_boxes/game.py:36-156   (3x3 boxes, 4x4 dots)
+//   gomoku     examples/gomoku/game.py:24-104
+//   terminal value  games/base.py:104-114
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace az {
+
+// terminal() results
+enum : int { T_NONE = 0, T_WIN_P1 = 1, T_WIN_P2 = 2, T_NO_WINNER = 3 };
+
+__device__ __forceinline__ uint32_t bit_at(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
+
+// ------------------------------------------------------------------------------------------
+// TicTacToe: word0 bits 0-8 = PLAYER1 stones (cell = row*3+col), bits 9-17 = PLAYER2 stones.
+struct TicTacToe {
+  static constexpr int A = 9, SW = 1, CS = 1, H = 3, WD = 3, HW = 9, CIN = 9, PMAX = 9;
+
+  __device__ static bool legal(const uint32_t *s, int a) {  // per lane
+    return (((s[0] | (s[0] >> 9)) >> a) & 1u) == 0u;
+  }
+  __device__ static bool same_player(const uint32_t *, int) { return false; }  // per lane
+  __device__ static int apply(uint32_t *s, int a, int player, int lane) {
+    uint32_t w = s[0] | (1u << (a + (player == 1 ? 0 : 9)));
+    __syncthreads();
+    if (lane == 0) s[0] = w;
+    __syncthreads();
+    return -player;
+  }
+  // after `mover` played `a`; nmoves = stones on the board
+  __device__ static int terminal(const uint32_t *s, int, int mover, int nmoves, int) {
+    const uint32_t b = (mover == 1 ? s[0] : (s[0] >> 9)) & 0x1FFu;
+    const uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
+    bool win = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) win |= (b & L[i]) == L[i];
+    if (win) return mover == 1 ? T_WIN_P1 : T_WIN_P2;
+    return nmoves == 9 ? T_NO_WINNER : T_NONE;
+  }
+  __device__ static float plane(const uint32_t *s, int, int cell) {  // per lane
+    return (float)(int)((s[0] >> cell) & 1u) - (float)(int)((s[0] >> (9 + cell)) & 1u);
+  }
+  // host: f32 state (3,3) -> words; returns false on a value outside {-1,0,1}
+  __host__ static bool encode(const float *st, uint32_t *w, int *nmoves) {
+    w[0] = 0; *nmoves = 0;
+    for (int i = 0; i < 9; ++i) {
+      if (st[i] == 1.0f) { w[0] |= 1u << i; ++*nmoves; }
+      else if (st[i] == -1.0f) { w[0] |= 1u << (9 + i); ++*nmoves; }
+      else if (st[i] != 0.0f) return false;
+    }
+    return true;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Dots and boxes: word0 bit a = edge of action a (a<12 horizontal r=a/3,c=a%3; else vertical
+// idx=a-12, r=idx/4, c=idx%4); word1 bits 0-8 boxes owned by PLAYER1 (box = r*3+c), bits 9-17 PLAYER2.
+struct Dab {
+  static constexpr int A = 24, SW = 2, CS = 3, H = 4, WD = 4, HW = 16, CIN = 25, PMAX = 24;
+
+  __host__ __device__ static uint32_t box_mask(int b) {
+    const int br = b / 3, bc = b % 3;
+    return (1u << (br * 3 + bc)) | (1u << ((br + 1) * 3 + bc)) | (1u << (12 + br * 4 + bc)) |
+           (1u << (12 + br * 4 + bc + 1));
+  }
+  // the (up to) two boxes an edge borders; -1 where there is none  (game.py:126-156)
+  __host__ __device__ static void adjacent(int a, int &b1, int &b2) {
+    if (a < 12) {
+      const int r = a / 3, c = a % 3;
+      b1 = r > 0 ? (r - 1) * 3 + c : -1;
+      b2 = r < 3 ? r * 3 + c : -1;
+    } else {
+      const int idx = a - 12, r = idx / 4, c = idx % 4;
+      b1 = c > 0 ? r * 3 + c - 1 : -1;
+      b2 = c < 3 ? r * 3 + c : -1;
+    }
+  }
+  // boxes that playing `a` completes (bit b), given edges e and owners o
+  __host__ __device__ static uint32_t completed(uint32_t e, uint32_t o, int a) {
+    int b1, b2;
+    adjacent(a, b1, b2);
+    const uint32_t e2 = e | (1u << a), owned = (o | (o >> 9)) & 0x1FFu;
+    uint32_t done = 0;
+    if (b1 >= 0 && !((owned >> b1) & 1u) && (e2 & box_mask(b1)) == box_mask(b1)) done |= 1u << b1;
+    if (b2 >= 0 && !((owned >> b2) & 1u) && (e2 & box_mask(b2)) == box_mask(b2)) done |= 1u << b2;
+    return done;
+  }
+  __device__ static bool legal(const uint32_t *s, int a) { return ((s[0] >> a) & 1u) == 0u; }
+  __device__ static bool same_player(const uint32_t *s, int a) { return completed(s[0], s[1], a) != 0u; }
+  __device__ static int apply(uint32_t *s, int a, int player, int lane) {
+    const uint32_t e = s[0], o = s[1];
+    const uint32_t done = completed(e, o, a);
+    __syncthreads();
+    if (lane == 0) {
+      s[0] = e | (1u << a);
+      s[1] = o | (done << (player == 1 ? 0 : 9));
+    }
+    __syncthreads();
+    return done ? player : -player;
+  }
+  __device__ static int terminal(const uint32_t *s, int, int, int, int) {
+    if ((s[0] & 0xFFFFFFu) != 0xFFFFFFu) return T_NONE;
+    const int p1 = __popc(s[1] & 0x1FFu), p2 = __popc((s[1] >> 9) & 0x1FFu);
+    return p1 > p2 ? T_WIN_P1 : (p2 > p1 ? T_WIN_P2 : T_NO_WINNER);
+  }
+  __device__ static float plane(const uint32_t *s, int ch, int cell) {
+    const int r = cell >> 2, c = cell & 3;
+    if (ch == 0) return (c < 3) ? (float)(int)((s[0] >> (r * 3 + c)) & 1u) : 0.0f;
+    if (ch == 1) return (r < 3) ? (float)(int)((s[0] >> (12 + r * 4 + c)) & 1u) : 0.0f;
+    if (r < 3 && c < 3)
+      return (float)(int)((s[1] >> (r * 3 + c)) & 1u) - (float)(int)((s[1] >> (9 + r * 3 + c)) & 1u);
+    return 0.0f;
+  }
+  __host__ static bool encode(const float *st, uint32_t *w, int *nmoves) {
+    w[0] = w[1] = 0; *nmoves = 0;
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) {
+        const float h = st[r * 4 + c], v = st[16 + r * 4 + c], o = st[32 + r * 4 + c];
+        if (c < 3) { if (h == 1.0f) { w[0] |= 1u << (r * 3 + c); ++*nmoves; } else if (h != 0.0f) return false; }
+        else if (h != 0.0f) return false;
+        if (r < 3) { if (v == 1.0f) { w[0] |= 1u << (12 + r * 4 + c); ++*nmoves; } else if (v != 0.0f) return false; }
+        else if (v != 0.0f) return false;
+        if (r < 3 && c < 3) {
+          if (o == 1.0f) w[1] |= 1u << (r * 3 + c);
+          else if (o == -1.0f) w[1] |= 1u << (9 + r * 3 + c);
+          else if (o != 0.0f) return false;
+        } else if (o != 0.0f) return false;
+      }
+    return true;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Gomoku NxN: words [0,WC) bit a = PLAYER1 stone at cell a = row*N+col; words [WC,2WC) PLAYER2.
+template <int N>
+struct Gomoku {
+  static constexpr int A = N * N, WC = (A + 31) / 32, SW = 2 * WC, CS = 1, H = N, WD = N, HW = A,
+                       CIN = 9, PMAX = A;
+
+  __device__ static bool legal(const uint32_t *s, int a) { return (bit_at(s, a) | bit_at(s + WC, a)) == 0u; }
+  __device__ static bool same_player(const uint32_t *, int) { return false; }
+  __device__ static int apply(uint32_t *s, int a, int player, int lane) {
+    const int wi = (player == 1 ? 0 : WC) + (a >> 5);
+    const uint32_t w = s[wi] | (1u << (a & 31));
+    __syncthreads();
+    if (lane == 0) s[wi] = w;
+    __syncthreads();
+    return -player;
+  }
+  // Only the mover can have made a five (the position before was not terminal), so the row-major
+  // scan of the reference (game.py:62-89) reduces to the four lines through the new stone.
+  // Lane l < 36 looks at direction l/9, offset l%9-4; any 5 consecutive set bits in a 9-window win
+  // (six or more in a row count, as in the reference).
+  __device__ static int terminal(const uint32_t *s, int a, int mover, int nmoves, int lane) {
+    const uint32_t *mine = s + (mover == 1 ? 0 : WC);
+    const int r = a / N, c = a % N;
+    bool bit = false;
+    if (lane < 36) {
+      const int d = lane / 9, k = lane % 9 - 4;
+      const int dr = (d == 0) ? 0 : 1, dc = (d == 0) ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1));
+      const int rr = r + k * dr, cc = c + k * dc;
+      if (rr >= 0 && rr < N && cc >= 0 && cc < N) bit = bit_at(mine, rr * N + cc) != 0u;
+    }
+    const unsigned long long m = __ballot(bit);
+    bool win = false;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      uint32_t w = (uint32_t)(m >> (9 * d)) & 0x1FFu;
+      w = w & (w >> 1) & (w >> 2) & (w >> 3) & (w >> 4);
+      win |= (w != 0u);
+    }
+    if (win) return mover == 1 ? T_WIN_P1 : T_WIN_P2;
+    return nmoves == A ? T_NO_WINNER : T_NONE;
+  }
+  __device__ static float plane(const uint32_t *s, int, int cell) {
+    return (float)(int)bit_at(s, cell) - (float)(int)bit_at(s + WC, cell);
+  }
+  __host__ static bool encode(const float *st, uint32_t *w, int *nmoves) {
+    for (int i = 0; i < SW; ++i) w[i] = 0;
+    *nmoves = 0;
+    for (int i = 0; i < A; ++i) {
+      if (st[i] == 1.0f) { w[i >> 5] |= 1u << (i & 31); ++*nmoves; }
+      else if (st[i] == -1.0f) { w[WC + (i >> 5)] |= 1u << (i & 31); ++*nmoves; }
+      else if (st[i] != 0.0f) return false;
+    }
+    return true;
+  }
+};
+
+// games/base.py:104-114 from the point of view of `player` (the player to move at that node)
+__device__ __forceinline__ float terminal_value(int term, int player) {
+  if (term == T_WIN_P1) return player == 1 ? 1.0f : -1.0f;
+  if (term == T_WIN_P2) return player == -1 ? 1.0f : -1.0f;
+  return 0.0f;
+}
+
+}  // namespace az

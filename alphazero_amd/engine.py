@@ -1,0 +1,281 @@
+"""ctypes binding of libaz_engine.so (C ABI: include/az_engine.h) on torch device tensors.
+
+PyTorch is plumbing here: it owns the caller-side device buffers and the stream.  Every compute step
+is a hand-written HIP kernel inside the library; if the library is missing this module raises -- there
+is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import torch
+
+from . import _build
+
+GAME_TICTACTOE, GAME_DAB, GAME_GOMOKU = 0, 1, 2
+NN_F32, NN_BF16, NN_F16 = 0, 1, 2
+_NN_DTYPES = {torch.float32: NN_F32, torch.bfloat16: NN_BF16, torch.float16: NN_F16}
+
+
+class AzConfig(C.Structure):
+    _fields_ = [("game", C.c_int32), ("board_size", C.c_int32), ("n_slots", C.c_int32), ("max_sims", C.c_int32),
+                ("c_puct", C.c_float), ("epsilon", C.c_float), ("nn_dtype", C.c_int32), ("device", C.c_int32),
+                ("edge_cap", C.c_int32), ("reserved", C.c_int32)]
+
+
+class AzDims(C.Structure):
+    _fields_ = [("n_action", C.c_int32), ("state_channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+                ("nn_channels", C.c_int32), ("max_plies", C.c_int32), ("state_words", C.c_int32),
+                ("edge_cap", C.c_int32), ("node_cap", C.c_int32), ("depth_cap", C.c_int32), ("n_slots", C.c_int32),
+                ("reserved", C.c_int32), ("device_bytes", C.c_int64)]
+
+
+class AzStats(C.Structure):
+    _fields_ = [("sims", C.c_uint64), ("sum_depth", C.c_uint64), ("sum_children", C.c_uint64),
+                ("evals", C.c_uint64), ("terminals", C.c_uint64), ("expanded_edges", C.c_uint64)]
+
+
+EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check", "az_reset_games",
+           "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_root_policy",
+           "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
+           "az_reset_stats", "az_eval_hash"]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load the in-tree HIP library; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -m alphazero_amd._build` (hipcc, gfx950). "
+            "alphazero_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.az_create.argtypes = [C.POINTER(AzConfig), C.POINTER(vp)]
+    lib.az_destroy.argtypes = [vp]
+    lib.az_get_dims.argtypes = [vp, C.POINTER(AzDims)]
+    lib.az_last_error.argtypes = [vp]
+    lib.az_last_error.restype = C.c_char_p
+    lib.az_check.argtypes = [vp, vp]
+    lib.az_reset_games.argtypes = [vp, vp, vp]
+    lib.az_set_position.argtypes = [vp, C.c_int32, vp, C.c_int32, vp]
+    lib.az_begin_search.argtypes = [vp, vp]
+    lib.az_select_gather.argtypes = [vp, vp, vp]
+    lib.az_expand_backup.argtypes = [vp, vp, vp, vp, vp]
+    lib.az_root_policy.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.az_root_nn_state.argtypes = [vp, vp, vp]
+    lib.az_play_moves.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.az_game_info.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.az_emit_samples.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp, vp]
+    lib.az_read_stats.argtypes = [vp, C.POINTER(AzStats), vp]
+    lib.az_reset_stats.argtypes = [vp, vp]
+    lib.az_eval_hash.argtypes = [vp, vp, C.c_float, vp, vp, vp]
+    for name in EXPORTS:
+        if name != "az_last_error":
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+@dataclass
+class Dims:
+    n_action: int
+    state_channels: int
+    height: int
+    width: int
+    nn_channels: int
+    max_plies: int
+    state_words: int
+    edge_cap: int
+    node_cap: int
+    depth_cap: int
+    n_slots: int
+    device_bytes: int
+
+    @property
+    def nn_numel(self) -> int:
+        return self.nn_channels * self.height * self.width
+
+    @property
+    def state_numel(self) -> int:
+        return self.state_channels * self.height * self.width
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """Many concurrent games, one search tree each, resident on one GPU."""
+
+    def __init__(self, game: int, n_slots: int, max_sims: int, board_size: int = 15, c_puct: float = 1.0,
+                 epsilon: float = 0.25, nn_dtype: torch.dtype = torch.float32, device=None, edge_cap: int = 0):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise EngineError("no GPU visible: the engine has no CPU path")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise EngineError(f"engine needs a cuda (HIP) device, got {self.device}")
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        self.nn_dtype = nn_dtype
+        cfg = AzConfig(game, board_size, n_slots, max_sims, c_puct, epsilon, _NN_DTYPES[nn_dtype], dev_index,
+                       edge_cap, 0)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.az_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"az_create failed ({rc}): {self.lib.az_last_error(None).decode()}")
+        self._h = h
+        d = AzDims()
+        self._ck(self.lib.az_get_dims(self._h, C.byref(d)))
+        self.dims = Dims(d.n_action, d.state_channels, d.height, d.width, d.nn_channels, d.max_plies,
+                         d.state_words, d.edge_cap, d.node_cap, d.depth_cap, d.n_slots, d.device_bytes)
+        self.game = game
+        self.n_slots = n_slots
+        self.max_sims = max_sims
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc):
+        if rc != 0:
+            raise EngineError(f"az call failed ({rc}): {self.lib.az_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _expect(self, t, shape, dtype, name):
+        if t is None:
+            return
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+            raise EngineError(f"{name}: expected contiguous {dtype} {tuple(shape)} on {self.device}, got "
+                              f"{t.dtype} {tuple(t.shape)} on {t.device} (contiguous={t.is_contiguous()})")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.az_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def new(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def new_nn_input(self):
+        d = self.dims
+        return torch.zeros(self.n_slots, d.nn_channels, d.height, d.width, dtype=self.nn_dtype, device=self.device)
+
+    # ------------------------------------------------------------------ entry points
+    def check(self):
+        self._ck(self.lib.az_check(self._h, self._stream()))
+
+    def reset_games(self, mask=None):
+        self._expect(mask, (self.n_slots,), torch.uint8, "mask")
+        self._ck(self.lib.az_reset_games(self._h, _ptr(mask), self._stream()))
+
+    def set_position(self, slot: int, history, root_player: int):
+        h = torch.as_tensor(history, dtype=torch.float32, device="cpu").contiguous()
+        if h.numel() != 8 * self.dims.state_numel:
+            raise EngineError(f"history must hold 8 states of {self.dims.state_numel} values")
+        self._ck(self.lib.az_set_position(self._h, slot, C.c_void_p(h.data_ptr()), int(root_player), self._stream()))
+
+    def begin_search(self):
+        self._ck(self.lib.az_begin_search(self._h, self._stream()))
+
+    def select_gather(self, nn_input):
+        d = self.dims
+        self._expect(nn_input, (self.n_slots, d.nn_channels, d.height, d.width), self.nn_dtype, "nn_input")
+        self._ck(self.lib.az_select_gather(self._h, _ptr(nn_input), self._stream()))
+
+    def expand_backup(self, logits, values, noise=None):
+        A = self.dims.n_action
+        self._expect(logits, (self.n_slots, A), torch.float32, "logits")
+        if values.dim() == 2:
+            values = values.view(-1)
+        self._expect(values, (self.n_slots,), torch.float32, "values")
+        self._expect(noise, (self.n_slots, A), torch.float32, "noise")
+        self._ck(self.lib.az_expand_backup(self._h, _ptr(logits), _ptr(values), _ptr(noise), self._stream()))
+
+    def root_policy(self, pi=None, visits=None, child_q=None, root_prior=None):
+        A, G = self.dims.n_action, self.n_slots
+        pi = self.new(G, A) if pi is None else pi
+        self._expect(pi, (G, A), torch.float32, "pi")
+        self._expect(visits, (G, A), torch.int32, "visits")
+        self._expect(child_q, (G, A), torch.float64, "child_q")
+        self._expect(root_prior, (G, A), torch.float32, "root_prior")
+        self._ck(self.lib.az_root_policy(self._h, _ptr(pi), _ptr(visits), _ptr(child_q), _ptr(root_prior),
+                                         self._stream()))
+        return pi
+
+    def root_nn_state(self, out=None):
+        d = self.dims
+        out = torch.zeros(self.n_slots, d.nn_channels, d.height, d.width, device=self.device) if out is None else out
+        self._expect(out, (self.n_slots, d.nn_channels, d.height, d.width), torch.float32, "nn_state")
+        self._ck(self.lib.az_root_nn_state(self._h, _ptr(out), self._stream()))
+        return out
+
+    def play_moves(self, inv_tao, expo, forced=None, actions=None, done=None):
+        A, G = self.dims.n_action, self.n_slots
+        actions = self.new(G, dtype=torch.int32) if actions is None else actions
+        done = self.new(G, dtype=torch.uint8) if done is None else done
+        self._expect(inv_tao, (G,), torch.float32, "inv_tao")
+        self._expect(expo, (G, A), torch.float32, "expo")
+        self._expect(forced, (G,), torch.int32, "forced")
+        self._expect(actions, (G,), torch.int32, "actions")
+        self._expect(done, (G,), torch.uint8, "done")
+        self._ck(self.lib.az_play_moves(self._h, _ptr(inv_tao), _ptr(expo), _ptr(forced), _ptr(actions), _ptr(done),
+                                        self._stream()))
+        return actions, done
+
+    def game_info(self):
+        G = self.n_slots
+        plies, player = self.new(G, dtype=torch.int32), self.new(G, dtype=torch.int32)
+        active, result = self.new(G, dtype=torch.uint8), self.new(G)
+        self._ck(self.lib.az_game_info(self._h, _ptr(plies), _ptr(player), _ptr(active), _ptr(result), self._stream()))
+        return plies, player, active, result
+
+    def emit_samples(self, slots, plies):
+        """slots: finished slot ids (list / 1-D int tensor, host); plies: their lengths.
+        -> (states (n, C_in*H*W), pis (n, A), z (n,), offsets) in the reference's put order per game."""
+        d = self.dims
+        slots_h = torch.as_tensor(slots, dtype=torch.int32, device="cpu").reshape(-1)
+        plies_h = torch.as_tensor(plies, dtype=torch.int32, device="cpu").reshape(-1)
+        n = int(slots_h.numel())
+        offs = torch.zeros(n + 1, dtype=torch.int32)
+        if n:
+            offs[1:] = torch.cumsum(plies_h, 0)
+        total = int(offs[-1])
+        states = self.new(total, d.nn_numel)
+        pis = self.new(total, d.n_action)
+        z = self.new(total)
+        if n:
+            s_dev = slots_h.to(self.device)
+            o_dev = offs.to(self.device)
+            self._ck(self.lib.az_emit_samples(self._h, _ptr(s_dev), _ptr(o_dev), n, _ptr(states), _ptr(pis), _ptr(z),
+                                              self._stream()))
+        return states, pis, z, offs
+
+    def read_stats(self) -> dict:
+        s = AzStats()
+        self._ck(self.lib.az_read_stats(self._h, C.byref(s), self._stream()))
+        return {k: int(getattr(s, k)) for k, _ in AzStats._fields_}
+
+    def reset_stats(self):
+        self._ck(self.lib.az_reset_stats(self._h, self._stream()))
+
+    def eval_hash(self, nn_input, logits, values, scale: float = 4.0):
+        self._ck(self.lib.az_eval_hash(self._h, _ptr(nn_input), C.c_float(scale), _ptr(logits), _ptr(values),
+                                       self._stream()))

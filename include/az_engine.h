@@ -1,0 +1,162 @@
+/*
+ * az_engine.h -- C ABI of the MI355X (gfx950) many-tree self-play engine.
+ *
+ * The reference (BlueRose2020/alphazero) is pure Python and has no FFI of its own; the boundary it
+ * does have is three duck-typed Python contracts.  This header is the native
+ * layer underneath them: each entry point replaces the interpreted code cited next to it, for
+ * thousands of games at once.  Host code (alphazero_amd/engine.py) binds it with ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative AZ_E* code on failure; no exceptions cross
+ *     the ABI; az_last_error() returns a message for the last failure on that engine;
+ *   - pointers named *_dev are device pointers owned by the CALLER (e.g. torch tensors) and only
+ *     borrowed for the call; tree and game arrays are owned by the engine;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are asynchronous
+ *     on that stream unless stated otherwise; one host thread per engine;
+ *   - one engine lives on one GPU (az_config.device); games never move between engines.
+ *   - there is no CPU fallback: az_create fails if no HIP device is usable.
+ */
+#ifndef AZ_ENGINE_H
+#define AZ_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_GAME_TICTACTOE 0 /* examples/tictactoe/game.py   S=(3,3)    A=9   */
+#define AZ_GAME_DAB 1       /* examples/dots_and_boxes/game.py S=(3,4,4) A=24 (3x3 boxes) */
+#define AZ_GAME_GOMOKU 2    /* examples/gomoku/game.py      S=(N,N)    A=N*N, N in {9,15} */
+
+#define AZ_NN_F32 0
+#define AZ_NN_BF16 1
+#define AZ_NN_F16 2
+
+#define AZ_OK 0
+#define AZ_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define AZ_ENOMEM (-2)   /* device allocation failed */
+#define AZ_EHIP (-3)     /* a HIP call failed (message in az_last_error) */
+#define AZ_EDEVICE (-4)  /* a kernel flagged an internal error (capacity, illegal move) */
+
+typedef struct az_engine az_engine;
+
+typedef struct az_config {
+  int32_t game;        /* AZ_GAME_* */
+  int32_t board_size;  /* gomoku N; ignored otherwise */
+  int32_t n_slots;     /* concurrent games (one tree each) */
+  int32_t max_sims;    /* simulations per move the trees are sized for (TRAIN_NUM_SIMULATION) */
+  float c_puct;        /* config/basic.py:12 */
+  float epsilon;       /* config/basic.py:14, Dirichlet mix weight */
+  int32_t nn_dtype;    /* AZ_NN_*: element type of the NN-input batch the engine writes */
+  int32_t device;      /* HIP device ordinal */
+  int32_t edge_cap;    /* child records per tree; 0 = worst case max_sims * A */
+  int32_t reserved;
+} az_config;
+
+typedef struct az_dims {
+  int32_t n_action;       /* A */
+  int32_t state_channels; /* channels of one state (1 for 2-D states) */
+  int32_t height, width;
+  int32_t nn_channels;    /* C_in = 8 * state_channels + 1 (USE_HISTORY, HISTORY_LEN = 8) */
+  int32_t max_plies;
+  int32_t state_words;    /* u32 words of one bitboard state */
+  int32_t edge_cap, node_cap, depth_cap;
+  int32_t n_slots;
+  int32_t reserved;
+  int64_t device_bytes;   /* HBM held by the engine */
+} az_dims;
+
+/* counters summed over all slots since az_create (or the last az_reset_stats) */
+typedef struct az_stats {
+  uint64_t sims;          /* simulations run */
+  uint64_t sum_depth;     /* sum of selection depths (edges followed) */
+  uint64_t sum_children;  /* child records scanned by select */
+  uint64_t evals;         /* leaves that needed the network */
+  uint64_t terminals;     /* leaves that were terminal positions */
+  uint64_t expanded_edges;/* child records written by expand */
+} az_stats;
+
+/* Lifetime.  az_create sizes and allocates every array once; nothing else allocates. */
+int az_create(const az_config *cfg, az_engine **out);
+int az_destroy(az_engine *e);
+int az_get_dims(const az_engine *e, az_dims *out);
+const char *az_last_error(const az_engine *e); /* e == NULL: last az_create failure */
+int az_check(az_engine *e, void *stream);      /* synchronises; AZ_EDEVICE if a kernel flagged an error */
+
+/* games/base.py:15-20  BaseGame.reset(): initial state, PLAYER1 to move, history = 8x initial.
+ * mask_dev: n_slots bytes, non-zero = reset that slot; NULL = all slots. */
+int az_reset_games(az_engine *e, const uint8_t *mask_dev, void *stream);
+
+/* Load an arbitrary position into one slot (the MCTS.search(root_state, root_player,
+ * history_state) arguments, core/MCTS_alphazero.py:128-137).  history_host: 8 states of
+ * state_channels*height*width f32 each, oldest first, newest == root state (utils/history_manager.py:41-47).
+ * Host pointer; synchronous. */
+int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32_t root_player, void *stream);
+
+/* core/MCTS_alphazero.py:142  a fresh, unexpanded root for every active slot (no tree reuse). */
+int az_begin_search(az_engine *e, void *stream);
+
+/* One simulation's descent in every active tree: core/MCTS_alphazero.py:145-160 (history load, the
+ * select loop :149-154 = MCTSNode.select :59-78 + game next_state/is_terminal, terminal evaluation
+ * :157-158) and _node2nn_state :202-209.  Writes row g of nn_input_dev, shape
+ * (n_slots, nn_channels, height, width) of az_config.nn_dtype, for every slot whose leaf needs the
+ * network; other rows are left untouched. */
+int az_select_gather(az_engine *e, void *nn_input_dev, void *stream);
+
+/* The rest of that simulation: _get_prior :180-192 (softmax, Dirichlet mix at the root, legal mask,
+ * renormalise), MCTSNode.expand :43-57, value.item() :170 and _bacaward :194-200.
+ * logits_dev (n_slots, A) f32, values_dev (n_slots) f32: the model's outputs for the batch written by
+ * az_select_gather.  noise_dev (n_slots, A) f32: one Dirichlet(alpha) draw per slot, applied when the
+ * leaf is the root; NULL = use_Dirichlet False. */
+int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_dev,
+                     const float *noise_dev, void *stream);
+
+/* core/MCTS_alphazero.py:174-178: pi = visits / visits.sum() as (n_slots, A) f32.  Optional extras
+ * (NULL to skip): root child visits i32 (n_slots, A), child values f64 (n_slots, A) from the child's
+ * own view, the root prior f32 (n_slots, A). */
+int az_root_policy(az_engine *e, float *pi_dev, int32_t *visits_dev, double *child_q_dev,
+                   float *root_prior_dev, void *stream);
+
+/* training/self_play.py:38-56: the sample's nn_state = cat(history, player plane) of every active
+ * slot's current position, f32 (n_slots, nn_channels, height, width). */
+int az_root_nn_state(az_engine *e, float *nn_state_dev, void *stream);
+
+/* training/self_play.py:73-83 + games/base.py:22-33: w = pi ** (1/tao); action = multinomial(w, 1),
+ * taken as argmax(w / expo) over Exponential(1) draws (ATen's single-sample path); game.step(action);
+ * the position, pi (as visit counts) and player are appended to the slot's on-device trajectory.
+ * inv_tao_dev (n_slots) f32 = 1/tao per slot; expo_dev (n_slots, A) f32; forced_actions_dev
+ * (n_slots) i32 or NULL: when given and >= 0 that action is played instead of a sampled one.
+ * actions_dev (n_slots) i32 out (-1 for inactive slots); done_dev (n_slots) u8 out: 1 where the game
+ * just ended (the slot is then inactive until az_reset_games). */
+int az_play_moves(az_engine *e, const float *inv_tao_dev, const float *expo_dev,
+                  const int32_t *forced_actions_dev, int32_t *actions_dev, uint8_t *done_dev, void *stream);
+
+/* Per-slot game info, device-to-device copies into caller buffers (any may be NULL):
+ * plies i32, player to move i32, active u8, result f32 (outcome from the last mover's view,
+ * training/self_play.py:86-89; valid once done). */
+int az_game_info(az_engine *e, int32_t *plies_dev, int32_t *player_dev, uint8_t *active_dev,
+                 float *result_dev, void *stream);
+
+/* training/self_play.py:110-139 _generate_experience_date for n_games finished slots: for game i
+ * (slot slots_dev[i], T plies) writes T samples at rows offsets_dev[i] .. offsets_dev[i]+T-1, LAST
+ * position first (the reference's put order): nn_state f32 (rows, nn_channels*height*width), pi f32
+ * (rows, A), z f32 (rows). */
+int az_emit_samples(az_engine *e, const int32_t *slots_dev, const int32_t *offsets_dev, int32_t n_games,
+                    float *states_dev, float *pis_dev, float *z_dev, void *stream);
+
+/* Counters for the roofline (algorithmic bytes per simulation need the measured mean depth and mean
+ * children per visited node).  Synchronises. */
+int az_read_stats(az_engine *e, az_stats *out, void *stream);
+int az_reset_stats(az_engine *e, void *stream);
+
+/* No counterpart in the reference: a deterministic synthetic evaluator ("hash network") with exact
+ * f32 outputs, so tree parity can be tested bit for bit without a neural network and the tree
+ * kernels can be benchmarked alone.  Reads the batch written by az_select_gather. */
+int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *logits_dev,
+                 float *values_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZ_ENGINE_H */

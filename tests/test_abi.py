@@ -1,0 +1,37 @@
+"""CPU-side checks of the boundary: the C-ABI library exists, loads, and exports every symbol that
+include/az_engine.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+from .conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "az_engine.h")).read()
+    return sorted(set(re.findall(r"\b(az_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    from alphazero_amd import _build
+    from alphazero_amd.engine import EXPORTS
+
+    _build.build()
+    lib = ctypes.CDLL(_build.LIB)
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/az_engine.h but not exported"
+    assert sorted(EXPORTS) == names
+
+
+def test_create_rejects_bad_config_without_gpu():
+    from alphazero_amd.engine import AzConfig, load_library
+
+    lib = load_library()
+    h = ctypes.c_void_p()
+    bad = AzConfig(7, 15, 4, 10, 1.0, 0.25, 0, 0, 0, 0)
+    assert lib.az_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    assert b"unknown game" in lib.az_last_error(None)
+    bad = AzConfig(2, 13, 4, 10, 1.0, 0.25, 0, 0, 0, 0)
+    assert lib.az_create(ctypes.byref(bad), ctypes.byref(h)) == -1

@@ -1,0 +1,227 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bars (north_star): visit counts, chosen moves, transitions, NN-input tensors, z: bit-exact.
+Priors and Q: the engine and the oracle use the same arithmetic, so they are compared bit-exactly
+against the oracle, and at 1e-5 relative against the reference's recorded values.
+"""
+import numpy as np
+import pytest
+import torch
+
+from .conftest import game_of, load_cases
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [("tictactoe", 0, 3, 50), ("dab", 1, 3, 80), ("gomoku9", 2, 9, 120), ("gomoku15", 2, 15, 100)]
+
+
+def _engine(game, n, slots, sims, **kw):
+    from alphazero_amd import Engine
+
+    return Engine(game, slots, sims, board_size=n, device="cuda:0", **kw)
+
+
+def _random_position(oracle, game, n, n_moves, rng):
+    """-> (history (8, numel) oldest first, player to move) after n_moves random legal moves"""
+    d = oracle.dims(game, n)
+    while True:
+        s = np.zeros(d["numel"], np.float32)
+        hist = [s.copy() for _ in range(8)]
+        player, ok = 1, True
+        for _ in range(n_moves):
+            legal = np.nonzero(oracle.legal_mask(game, n, s))[0]
+            s, player = oracle.next_state(game, n, s, int(rng.choice(legal)), player)
+            hist = hist[1:] + [s.copy()]
+            if oracle.status(game, n, s)[0]:
+                ok = False
+                break
+        if ok:
+            return np.stack(hist), player
+
+
+def _run_search(eng, sims, evaluator, noise=None):
+    nn = eng.new_nn_input()
+    A, G = eng.dims.n_action, eng.n_slots
+    logits, values = eng.new(G, A), eng.new(G)
+    eng.begin_search()
+    for _ in range(sims):
+        eng.select_gather(nn)
+        evaluator(nn, logits, values)
+        eng.expand_backup(logits, values, noise)
+    visits = eng.new(G, A, dtype=torch.int32)
+    q = eng.new(G, A, dtype=torch.float64)
+    prior = eng.new(G, A)
+    pi = eng.root_policy(visits=visits, child_q=q, root_prior=prior)
+    eng.check()
+    return pi.cpu().numpy(), visits.cpu().numpy(), q.cpu().numpy(), prior.cpu().numpy()
+
+
+@pytest.mark.parametrize("name,game,n,sims", CONFIGS)
+@pytest.mark.parametrize("nn_dtype", [torch.float32, torch.bfloat16])
+def test_search_matches_oracle_hash_net(oracle, name, game, n, sims, nn_dtype):
+    rng = np.random.default_rng(hash(name) % 1000)
+    G = 24
+    d = oracle.dims(game, n)
+    eng = _engine(game, n, G, sims, nn_dtype=nn_dtype)
+    max_moves = {0: 6, 1: 20, 2: 30}[game]
+    pos = [_random_position(oracle, game, n, int(rng.integers(0, max_moves + 1)), rng) for _ in range(G)]
+    for g, (h, p) in enumerate(pos):
+        eng.set_position(g, h, p)
+    noise_np = rng.dirichlet([0.3] * d["A"], size=G).astype(np.float32)
+    noise = torch.from_numpy(noise_np).cuda()
+    scale = 6.0
+    pi, visits, q, prior = _run_search(eng, sims, lambda x, l, v: eng.eval_hash(x, l, v, scale), noise)
+    fn, ctx, _keep = oracle.hash_eval(scale)
+    for g, (h, p) in enumerate(pos):
+        r = oracle.search(game, n, h[-1], p, h, sims, fn, ctx, noise=noise_np[g])
+        assert np.array_equal(visits[g], r["visits"]), (name, g)
+        assert np.array_equal(q[g], r["child_q"]), (name, g)
+        assert np.array_equal(prior[g], r["root_prior"]), (name, g)
+        assert np.array_equal(pi[g], r["pi"]), (name, g)
+    st = eng.read_stats()
+    assert st["sims"] == G * sims and st["evals"] + st["terminals"] == st["sims"]
+
+
+SEARCH = load_cases("search.npz")
+
+
+@pytest.mark.parametrize("tag", sorted(SEARCH))
+def test_search_matches_reference_golden(oracle, tag):
+    """The reference's own recorded searches; the network is replayed from the recorded table."""
+    c = SEARCH[tag]
+    game, n = game_of(tag)
+    sims = int(c["num_sim"])
+    eng = _engine(game, n, 1, sims)
+    d = eng.dims
+    eng.set_position(0, c["history"].astype(np.float32), int(c["root_player"]))
+    table = {c["eval_in"][i].astype(np.float32).tobytes(): (c["eval_logits"][i], c["eval_value"][i])
+             for i in range(len(c["eval_in"]))}
+    hits = []
+
+    def evaluator(nn, logits, values):
+        key = nn[0].reshape(-1).cpu().numpy().tobytes()
+        if key in table:  # terminal leaves leave the row untouched
+            lg, v = table[key]
+            logits.copy_(torch.from_numpy(lg).view(1, -1))
+            values.copy_(torch.tensor([float(v)]))
+            hits.append(1)
+
+    noise = torch.from_numpy(c["noise"]).view(1, -1).cuda() if c["noise"].size else None
+    pi, visits, q, prior = _run_search(eng, sims, evaluator, noise)
+    assert np.array_equal(visits[0], c["visits"])
+    assert np.array_equal(pi[0], c["pi"])
+    np.testing.assert_allclose(q[0], c["child_q"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(prior[0], c["root_prior"], rtol=1e-5, atol=1e-9)
+    assert d.n_action == c["pi"].size
+
+
+def _self_play(eng, sims, evaluator, noise_tab, expo_tab, inv_tao):
+    """Plays every slot to the end; tables are (G, plies, A) host arrays indexed by the slot's ply."""
+    G, A = eng.n_slots, eng.dims.n_action
+    nn = eng.new_nn_input()
+    logits, values = eng.new(G, A), eng.new(G)
+    it = torch.full((G,), inv_tao, device="cuda")
+    acts = [[] for _ in range(G)]
+    plies_done = {}
+    ply = np.zeros(G, np.int64)
+    active = np.ones(G, bool)
+    while active.any():
+        noise = torch.from_numpy(np.stack([noise_tab[g, min(ply[g], noise_tab.shape[1] - 1)] for g in range(G)])).cuda()
+        expo = torch.from_numpy(np.stack([expo_tab[g, min(ply[g], expo_tab.shape[1] - 1)] for g in range(G)])).cuda()
+        eng.begin_search()
+        for _ in range(sims):
+            eng.select_gather(nn)
+            evaluator(nn, logits, values)
+            eng.expand_backup(logits, values, noise)
+        a, done = eng.play_moves(it, expo)
+        a, done = a.cpu().numpy(), done.cpu().numpy()
+        for g in range(G):
+            if active[g]:
+                acts[g].append(int(a[g]))
+                ply[g] += 1
+                if done[g]:
+                    active[g] = False
+                    plies_done[g] = int(ply[g])
+    eng.check()
+    return acts, plies_done
+
+
+@pytest.mark.parametrize("name,game,n,sims", [("tictactoe", 0, 3, 50), ("dab", 1, 3, 40), ("gomoku9", 2, 9, 30)])
+@pytest.mark.parametrize("tao", [1.0, 0.6])
+def test_self_play_matches_oracle_hash_net(oracle, name, game, n, sims, tao):
+    rng = np.random.default_rng(5 + int(tao * 10))
+    G = 12
+    d = oracle.dims(game, n)
+    A, P = d["A"], {0: 9, 1: 24, 2: 81}[game]
+    eng = _engine(game, n, G, sims)
+    noise_tab = rng.dirichlet([0.3] * A, size=(G, P)).astype(np.float32)
+    expo_tab = rng.exponential(1.0, size=(G, P, A)).astype(np.float32)
+    scale = 5.0
+    inv_tao = float(np.float32(1.0 / tao))
+    acts, plies = _self_play(eng, sims, lambda x, l, v: eng.eval_hash(x, l, v, scale), noise_tab, expo_tab, inv_tao)
+    slots = sorted(plies)
+    states, pis, z, offs = eng.emit_samples(slots, [plies[g] for g in slots])
+    _, _, _, result = eng.game_info()
+    states, pis, z, result = states.cpu().numpy(), pis.cpu().numpy(), z.cpu().numpy(), result.cpu().numpy()
+    fn, ctx, _keep = oracle.hash_eval(scale)
+    for i, g in enumerate(slots):
+        r = oracle.self_play(game, n, sims, tao, expo_tab[g], fn, ctx, noise=noise_tab[g], max_plies=P)
+        assert r["plies"] == plies[g] and list(r["actions"]) == acts[g], (name, g)
+        lo, hi = int(offs[i]), int(offs[i + 1])
+        assert np.array_equal(states[lo:hi], r["nn_states"][::-1])   # put order: last position first
+        assert np.array_equal(pis[lo:hi], r["pis"][::-1])
+        assert np.array_equal(z[lo:hi], r["z"][::-1])
+        assert result[g] == r["result"]
+
+
+SELFPLAY = load_cases("selfplay.npz")
+
+
+@pytest.mark.parametrize("tag", sorted(SELFPLAY))
+def test_self_play_matches_reference_golden(oracle, tag):
+    c = SELFPLAY[tag]
+    game, n = game_of(tag)
+    sims, tao = int(c["num_sim"]), float(c["tao"])
+    eng = _engine(game, n, 1, sims)
+    table = {c["eval_in"][i].astype(np.float32).tobytes(): (c["eval_logits"][i], c["eval_value"][i])
+             for i in range(len(c["eval_in"]))}
+
+    def evaluator(nn, logits, values):
+        key = nn[0].reshape(-1).cpu().numpy().tobytes()
+        if key in table:
+            lg, v = table[key]
+            logits.copy_(torch.from_numpy(lg).view(1, -1))
+            values.copy_(torch.tensor([float(v)]))
+
+    inv_tao = float(np.float32(1.0 / tao))
+    acts, plies = _self_play(eng, sims, evaluator, c["noise"][None], c["expo"][None], inv_tao)
+    assert acts[0] == list(c["actions"])
+    states, pis, z, _ = eng.emit_samples([0], [plies[0]])
+    assert np.array_equal(states.cpu().numpy().astype(np.int8), c["put_states"])
+    assert np.array_equal(pis.cpu().numpy(), c["put_pis"])
+    assert np.array_equal(z.cpu().numpy(), c["put_z"])
+
+
+def test_full_size_invariants():
+    """BASELINE config 4 shape (gomoku 15x15, 16384 trees): size-independent properties."""
+    from alphazero_amd import Engine
+
+    G, sims = 16384, 24
+    eng = Engine(2, G, sims, board_size=15, device="cuda:0", nn_dtype=torch.bfloat16)
+    nn = eng.new_nn_input()
+    A = eng.dims.n_action
+    logits, values = eng.new(G, A), eng.new(G)
+    eng.begin_search()
+    for _ in range(sims):
+        eng.select_gather(nn)
+        eng.eval_hash(nn, logits, values, 6.0)
+        eng.expand_backup(logits, values, None)
+    visits = eng.new(G, A, dtype=torch.int32)
+    pi = eng.root_policy(visits=visits)
+    eng.check()
+    assert bool((visits.sum(1) == sims - 1).all())          # root visited sims times, children sims-1
+    assert torch.allclose(pi.sum(1), torch.ones(G, device="cuda"), atol=1e-5)
+    # identical positions + identical evaluator => identical trees in every slot
+    assert bool((visits == visits[0:1]).all())
+    st = eng.read_stats()
+    assert st["sims"] == G * sims and st["evals"] == G * sims
