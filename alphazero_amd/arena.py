@@ -1,0 +1,226 @@
+"""Batched self-play driver: the host-side mirror of the reference's training/self_play.py.
+
+``ChessArena`` keeps the reference's constructor and methods (training/self_play.py:17-98) --
+``ChessArena(model_cls, game_cls, device)``, ``.model``, ``.self_play(tao, experience_pool)``,
+``.load_model(path)`` -- so ``training/alphazero_trainer.py`` (:182, :213, :368, :464) can use it
+unchanged, and adds ``self_play_many`` which plays thousands of games at once on one GPU.
+
+All tree, rule and sample arithmetic runs in libaz_engine.so (HIP); this file only sequences the
+calls, runs the policy/value network forward in PyTorch and hands samples to the pool.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence, Union
+
+import torch
+
+from .engine import Engine, EngineError, GAME_DAB, GAME_GOMOKU, GAME_TICTACTOE
+
+# config/basic.py:12-14, config/train_config.py:5,15-17
+C_PUCT = 1.0
+ALPHA = 0.3
+EPSILON = 0.25
+TRAIN_NUM_SIMULATION = 80
+START_TEMPERATURE, END_TEMPERATURE, TEMPERATURE_DECAY = 1.0, 0.1, 0.997
+
+
+def resolve_game(game_cls) -> tuple[int, int]:
+    """Map a ``BaseGame`` subclass (the reference's or alphazero_amd.games') to (engine game id, board).
+
+    Only games with a native rule kernel can run on the GPU ("arbitrary user games")."""
+    if hasattr(game_cls, "AZ_GAME"):
+        return game_cls.AZ_GAME
+    name = getattr(game_cls, "__name__", str(game_cls))
+    if "TicTacToe" in name:
+        return GAME_TICTACTOE, 3
+    if "DotsAndBoxes" in name:
+        if (getattr(game_cls, "BOX_ROWS", 3), getattr(game_cls, "BOX_COLS", 3)) != (3, 3):
+            raise EngineError("only the 3x3-box dots-and-boxes board has a native rule kernel")
+        return GAME_DAB, 3
+    if "Gomoku" in name:
+        n = int(getattr(game_cls, "BOARD_SIZE", 15))
+        if n not in (9, 15) or int(getattr(game_cls, "WIN_LENGTH", 5)) != 5:
+            raise EngineError("gomoku rule kernels exist for 9x9 and 15x15, five in a row")
+        return GAME_GOMOKU, n
+    raise EngineError(f"no native rule kernel for game class {name}")
+
+
+TaoSchedule = Union[float, Sequence[float], Callable[[int], float]]
+
+
+def reference_tao(game_index: int) -> float:
+    """temperature of a worker's game_index-th game (training/alphazero_trainer.py:186,214)"""
+    return max(START_TEMPERATURE * TEMPERATURE_DECAY ** game_index, END_TEMPERATURE)
+
+
+class SelfPlayRunner:
+    """One move of search + play for every active slot of an engine; used by ChessArena and bench.py."""
+
+    def __init__(self, engine: Engine, model: torch.nn.Module, num_sims: int, alpha: float = ALPHA,
+                 use_dirichlet: bool = True, reference_rng: bool = False, channels_last: bool = False):
+        if num_sims > engine.max_sims:
+            raise EngineError("num_sims exceeds the engine's max_sims")
+        self.e, self.model, self.num_sims = engine, model, num_sims
+        self.alpha, self.use_dirichlet, self.reference_rng = alpha, use_dirichlet, reference_rng
+        self.channels_last = channels_last
+        G, A = engine.n_slots, engine.dims.n_action
+        dev = engine.device
+        self.nn_input = engine.new_nn_input()
+        self.logits = torch.empty(G, A, device=dev)
+        self.values = torch.empty(G, device=dev)
+        self.noise = torch.empty(G, A, device=dev)
+        self.expo = torch.empty(G, A, device=dev)
+        self.actions = torch.empty(G, dtype=torch.int32, device=dev)
+        self.done = torch.empty(G, dtype=torch.uint8, device=dev)
+        self._conc = torch.full((G, A), alpha, device=dev)
+        p = next(model.parameters(), None)
+        self.model_device = p.device if p is not None else torch.device("cpu")
+        self.model_dtype = p.dtype if p is not None else torch.float32
+
+    # one model forward on the gathered batch -> self.logits / self.values (f32, engine device)
+    def evaluate(self) -> None:
+        x = self.nn_input
+        if x.device != self.model_device or x.dtype != self.model_dtype:
+            x = x.to(device=self.model_device, dtype=self.model_dtype)
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        with torch.inference_mode():
+            p, v = self.model(x)
+        self.logits.copy_(p.reshape(self.logits.shape), non_blocking=True)
+        self.values.copy_(v.reshape(-1), non_blocking=True)
+
+    def draw_noise(self) -> Optional[torch.Tensor]:
+        if not self.use_dirichlet:
+            return None
+        if self.reference_rng:  # the reference's draw: Dirichlet(ones_like(policy) * ALPHA).sample() on CPU, G == 1
+            from torch.distributions import Dirichlet
+
+            A = self.e.dims.n_action
+            self.noise.copy_(Dirichlet(torch.ones(self.e.n_slots, A) * self.alpha).sample())
+        else:
+            self.noise.copy_(torch._sample_dirichlet(self._conc))
+        return self.noise
+
+    def draw_expo(self) -> torch.Tensor:
+        if self.reference_rng:  # what torch.multinomial(w, 1) draws on CPU (ATen single-sample path)
+            self.expo.copy_(torch.empty(self.expo.shape).exponential_(1))
+        else:
+            self.expo.exponential_(1)
+        return self.expo
+
+    def search(self) -> None:
+        """num_sims simulations in every active tree (MCTS.search, core/MCTS_alphazero.py:128-178)"""
+        noise = self.draw_noise()
+        e = self.e
+        e.begin_search()
+        for _ in range(self.num_sims):
+            e.select_gather(self.nn_input)
+            self.evaluate()
+            e.expand_backup(self.logits, self.values, noise)
+
+    def move_round(self, inv_tao: torch.Tensor, forced: Optional[torch.Tensor] = None):
+        """search + temperature sampling + step, for every active slot (training/self_play.py:36-83)"""
+        self.search()
+        self.draw_expo()
+        self.e.play_moves(inv_tao, self.expo, forced, self.actions, self.done)
+        return self.actions, self.done
+
+
+class ChessArena:
+    """Drop-in for training/self_play.py:17 ``ChessArena`` backed by the HIP many-tree engine."""
+
+    def __init__(self, model_cls, game_cls, device: Optional[torch.device] = None, *, n_slots: int = 1024,
+                 num_simulation: int = TRAIN_NUM_SIMULATION, c_puct: float = C_PUCT, epsilon: float = EPSILON,
+                 alpha: float = ALPHA, nn_dtype: torch.dtype = torch.float32) -> None:
+        if not torch.cuda.is_available():
+            raise EngineError("alphazero_amd.ChessArena needs a GPU (no CPU fallback)")
+        # the reference defaults to SELF_PLAY_DEVICE = "cpu" (config/train_config.py:11); here the GPU is the point
+        self.device = torch.device(device) if device is not None and torch.device(device).type == "cuda" \
+            else torch.device("cuda", torch.cuda.current_device())
+        self.model = model_cls().to(self.device)
+        self.model.eval()
+        self.game_cls = game_cls
+        self.game_id, self.board_size = resolve_game(game_cls)
+        self.num_simulation, self.c_puct, self.epsilon, self.alpha = num_simulation, c_puct, epsilon, alpha
+        self.n_slots, self.nn_dtype = n_slots, nn_dtype
+        self._engines: dict[int, Engine] = {}
+        self.games_played = 0
+
+    def _engine(self, slots: int) -> Engine:
+        if slots not in self._engines:
+            self._engines[slots] = Engine(self.game_id, slots, self.num_simulation, board_size=self.board_size,
+                                          c_puct=self.c_puct, epsilon=self.epsilon, nn_dtype=self.nn_dtype,
+                                          device=self.device)
+        return self._engines[slots]
+
+    # ---- reference surface -------------------------------------------------------------------
+    def self_play(self, tao: float, experience_pool) -> None:
+        """One game (training/self_play.py:30-91).  Draws its Dirichlet / multinomial randomness from
+        torch's global CPU generator in the reference's order, so a seeded run replays the reference."""
+        self.self_play_many(1, float(tao), experience_pool, slots=1, reference_rng=True)
+
+    def load_model(self, file_path: str) -> None:
+        try:
+            with open(file_path, "rb") as f:
+                self.model.load_state_dict(torch.load(f, weights_only=True, map_location=self.device))
+        except Exception as exc:  # the reference raises FileExistsError here (training/self_play.py:97-98)
+            raise FileExistsError(f"model file {file_path} could not be loaded") from exc
+
+    # ---- batched extension --------------------------------------------------------------------
+    def self_play_many(self, n_games: int, tao: TaoSchedule, experience_pool, *, slots: Optional[int] = None,
+                       reference_rng: bool = False) -> dict:
+        """Play n_games games, up to ``slots`` at a time; every finished game's samples go to
+        ``experience_pool.put_tupule_experience`` exactly as training/self_play.py:110-139 puts them
+        ((1,C_in,H,W) f32, (1,A) f32, (1,) f32 CPU tensors, last position first).  Pools that offer
+        ``put_batch(states, pis, zs)`` get whole games' samples in one call instead."""
+        slots = min(slots or self.n_slots, n_games)
+        eng = self._engine(slots)
+        run = SelfPlayRunner(eng, self.model, self.num_simulation, alpha=self.alpha, reference_rng=reference_rng)
+        d = eng.dims
+
+        def tao_of(i: int) -> float:
+            if callable(tao):
+                return float(tao(i))
+            if isinstance(tao, (int, float)):
+                return float(tao)
+            return float(tao[i])
+
+        started = min(slots, n_games)
+        inv_tao_h = torch.tensor([1.0 / tao_of(self.games_played + i) if i < started else 1.0 for i in range(slots)],
+                                 dtype=torch.float32)
+        inv_tao = inv_tao_h.to(eng.device)
+        eng.reset_games(None)
+        finished = samples = 0
+        put_batch = getattr(experience_pool, "put_batch", None)
+        while finished < n_games:
+            _, done = run.move_round(inv_tao)
+            done_h = done.cpu()
+            idx = torch.nonzero(done_h).reshape(-1)
+            if idx.numel() == 0:
+                continue
+            plies, _, _, _ = eng.game_info()
+            plies_h = plies.cpu()[idx]
+            states, pis, zs, offs = eng.emit_samples(idx.to(torch.int32), plies_h)
+            states_h = states.view(-1, d.nn_channels, d.height, d.width).cpu()
+            pis_h, zs_h = pis.cpu(), zs.cpu()
+            if put_batch is not None:
+                put_batch(states_h, pis_h, zs_h)
+            else:
+                for k in range(states_h.shape[0]):
+                    experience_pool.put_tupule_experience(
+                        (states_h[k:k + 1].clone(), pis_h[k:k + 1].clone(), zs_h[k:k + 1].clone()))
+            samples += int(states_h.shape[0])
+            finished += int(idx.numel())
+            # restart finished slots while games remain (slot recycling)
+            restart = torch.zeros(slots, dtype=torch.uint8)
+            for s in idx.tolist():
+                if started < n_games:
+                    restart[s] = 1
+                    inv_tao_h[s] = 1.0 / tao_of(self.games_played + started)
+                    started += 1
+            if bool(restart.any()):
+                inv_tao.copy_(inv_tao_h)
+                eng.reset_games(restart.to(eng.device))
+        eng.check()
+        self.games_played += n_games
+        return {"games": n_games, "samples": samples}

@@ -1,0 +1,118 @@
+"""Policy/value networks obeying the reference's model contract (nn_models/base.py:12-29):
+
+    forward(x: (B, C_in, H, W) f32) -> (logits (B, A), value (B, 1) in [-1, 1])
+           = policy_head(shared_layers(x)), value_head(shared_layers(x))
+
+The dense forward stays in PyTorch-ROCm (MFMA via MIOpen/hipBLASLt); the engine only needs the
+contract.  Any reference ``BaseModel`` subclass works unchanged.  The nets here exist because the
+reference does not travel to the GPU box: they rebuild the reference's example architectures
+(examples/tictactoe/model.py, examples/dots_and_boxes/model.py, examples/gomoku/model.py) with the
+SAME parameter names, so a reference checkpoint (result/models/*/last_model.pth) loads with
+``load_state_dict``; GomokuNet additionally takes the board size / width / depth as arguments
+(the reference hard-codes 15 / 64 / 2, examples/gomoku/model.py:48-51), which is how BASELINE
+configs 3 and 5 (9x9 board, deep tower) are expressed.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+HISTORY_LEN = 8  # config/basic.py:10
+
+
+class DualHeadNet(nn.Module):
+    """shared tower + two heads; attribute names follow the reference so checkpoints interchange."""
+
+    _shared_layers: nn.Sequential
+    _policy_head: nn.Sequential
+    _value_head: nn.Sequential
+
+    @property
+    def shared_layers(self) -> nn.Sequential:
+        return self._shared_layers
+
+    def policy_head(self, x: torch.Tensor) -> torch.Tensor:
+        return self._policy_head(x)
+
+    def value_head(self, x: torch.Tensor) -> torch.Tensor:
+        return self._value_head(x)
+
+    def forward(self, x: torch.Tensor):
+        h = self.shared_layers(x)
+        return self.policy_head(h), self.value_head(h)
+
+
+def _mlp_value(n_in: int) -> list[nn.Module]:
+    return [nn.Linear(n_in, 64), nn.ReLU(), nn.Linear(64, 1), nn.Tanh()]
+
+
+class TicTacToeNet(DualHeadNet):
+    """(B,9,3,3) -> (B,9),(B,1); 154,186 parameters."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        c = 64
+        self._shared_layers = nn.Sequential(nn.Conv2d(HISTORY_LEN + 1, c, 3, padding=1), nn.ReLU(),
+                                            nn.Conv2d(c, c, 3, padding=1), nn.ReLU())
+        self._policy_head = nn.Sequential(nn.Flatten(1), nn.Linear(c * 9, 128), nn.ReLU(), nn.Linear(128, 9))
+        self._value_head = nn.Sequential(nn.Flatten(1), *_mlp_value(c * 9))
+
+
+class DotsAndBoxesNet(DualHeadNet):
+    """(B,25,4,4) -> (B,24),(B,1); 53,532 parameters."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        c, hw = 64, 16
+        self._shared_layers = nn.Sequential(nn.Conv2d(HISTORY_LEN * 3 + 1, c, 3, padding=1), nn.ReLU(),
+                                            nn.Conv2d(c, c, 3, padding=1), nn.ReLU())
+        self._policy_head = nn.Sequential(nn.Conv2d(c, 2, 1), nn.ReLU(), nn.Flatten(1), nn.Linear(2 * hw, 24))
+        self._value_head = nn.Sequential(nn.Conv2d(c, 1, 1), nn.ReLU(), nn.Flatten(1), *_mlp_value(hw))
+
+
+class _Res(nn.Module):
+    def __init__(self, c: int) -> None:
+        super().__init__()
+        self._conv1 = nn.Conv2d(c, c, 3, padding=1, bias=False)
+        self._bn1 = nn.BatchNorm2d(c)
+        self._conv2 = nn.Conv2d(c, c, 3, padding=1, bias=False)
+        self._bn2 = nn.BatchNorm2d(c)
+        self._relu = nn.ReLU()
+
+    def forward(self, x):
+        y = self._relu(self._bn1(self._conv1(x)))
+        y = self._bn2(self._conv2(y))
+        return self._relu(y + x)
+
+
+class GomokuNet(DualHeadNet):
+    """ResNet tower; defaults = the reference GomokuModel (15x15, 64 ch, 2 blocks, 233,257 params)."""
+
+    def __init__(self, board_size: int = 15, channels: int = 64, blocks: int = 2) -> None:
+        super().__init__()
+        a = board_size * board_size
+        self.board_size = board_size
+        self._shared_layers = nn.Sequential(
+            nn.Conv2d(HISTORY_LEN + 1, channels, 3, padding=1, bias=False), nn.BatchNorm2d(channels), nn.ReLU(),
+            *[_Res(channels) for _ in range(blocks)])
+        self._policy_head = nn.Sequential(nn.Conv2d(channels, 1, 1, bias=False), nn.BatchNorm2d(1), nn.ReLU(),
+                                          nn.Flatten(1), nn.Linear(a, a))
+        self._value_head = nn.Sequential(nn.Conv2d(channels, 2, 1, bias=False), nn.BatchNorm2d(2), nn.ReLU(),
+                                         nn.Flatten(1), *_mlp_value(2 * a))
+
+    def flops_per_eval(self) -> float:
+        """multiply-adds x2 of one forward (convs + linears), for MFMA utilisation reporting"""
+        total = 0.0
+        hw = self.board_size ** 2
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                total += 2.0 * hw * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
+            elif isinstance(m, nn.Linear):
+                total += 2.0 * m.in_features * m.out_features
+        return total
+
+
+def flat_parameters(model: nn.Module) -> list[torch.Tensor]:
+    """parameters + buffers in state_dict order: what a weight publish has to move
+    (training/alphazero_trainer.py:53-66 moves the whole state_dict)."""
+    return [t for t in model.state_dict().values() if t.is_floating_point() or t.dtype == torch.long]

@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""bench.py -- MCTS simulations/s (+ self-play games/s) of the HIP many-tree engine on MI355X.
+
+  python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json metric: "MCTS sims/sec + self-play games/sec, gomoku 15x15"; configs[3]):
+gomoku 15x15, 400 simulations per move, 16,384 concurrent games per GPU, the reference's GomokuModel
+(64 ch, 2 residual blocks) with random-init weights (seed 0), synthetic self-play (no dataset needed).
+One STEP = one move of self-play for every game on the GPU: Dirichlet draw, 400 x (select+gather ->
+network forward on the 16,384-position batch -> expand+backup), temperature sampling, game step,
+emission of finished games' (state, pi, z) samples into a pinned host ring, slot recycling.
+So one step = slots x 400 simulations per GPU.  Inputs live in HBM; only finished samples cross PCIe.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the dominant hand-written tree kernel (k_select_gather): algorithmic bytes per launch
+                  / mean launch time measured with HIP events on the launch stream, vs 8 TB/s HBM.
+  nn_eval      -- the network forward (PyTorch/MIOpen, MFMA): achieved TFLOP/s vs 2.5 PFLOP/s dense bf16.
+  cpu_baseline -- the CPU oracle (oracle/, "port" of the reference path, proven equal to it on the
+                  golden fixtures) timed on this box's host cores with the same network on torch-CPU.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (game id, board, sims/move, slots per GPU, net kwargs)
+    "gomoku15": (2, 15, 400, 16384, dict(board_size=15, channels=64, blocks=2)),
+    "gomoku9": (2, 9, 200, 4096, dict(board_size=9, channels=64, blocks=2)),
+    "dab": (1, 3, 80, 3000, {}),
+    "tictactoe": (0, 3, 50, 1000, {}),
+}
+
+
+def make_model(workload: str):
+    import torch
+    from alphazero_amd import nets
+
+    torch.manual_seed(0)
+    game = WORKLOADS[workload][0]
+    if game == 2:
+        return nets.GomokuNet(**WORKLOADS[workload][4]).eval()
+    return (nets.DotsAndBoxesNet() if game == 1 else nets.TicTacToeNet()).eval()
+
+
+# ------------------------------------------------------------------------------ CPU baseline ----
+def _cpu_worker(args):
+    """One single-threaded self-play worker on the CPU oracle (mirrors _self_player_worker,
+    training/alphazero_trainer.py:164-221: torch.set_num_threads(1), own seed)."""
+    workload, seed, budget_s = args
+    import numpy as np
+    import torch
+
+    torch.set_num_threads(1)
+    from oracle import az_oracle as O
+
+    game, n, sims, _, _ = WORKLOADS[workload]
+    model = make_model(workload)
+    d = O.dims(game, n)
+    ev = O.torch_eval(model, (d["cin"], d["H"], d["W"]))
+    rng = np.random.default_rng(seed)
+    A = d["A"]
+    done_sims = 0
+    games = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        s = np.zeros(d["numel"], np.float32)
+        hist = np.zeros((8, d["numel"]), np.float32)
+        player = 1
+        while time.perf_counter() - t0 < budget_s:
+            noise = rng.dirichlet([0.3] * A).astype(np.float32)
+            r = O.search(game, n, s, player, hist, sims, ev, noise=noise)
+            done_sims += sims
+            expo = rng.exponential(1.0, A).astype(np.float32)
+            a = int(np.argmax(r["pi"] / expo))
+            s, player = O.next_state(game, n, s, a, player)
+            hist = np.concatenate([hist[1:], s[None]])
+            if O.status(game, n, s)[0]:
+                games += 1
+                break
+    return done_sims, games, time.perf_counter() - t0
+
+
+def cpu_baseline(workload: str, budget_s: float = 12.0) -> dict:
+    import multiprocessing as mp
+
+    from oracle import az_oracle as O
+
+    O.build()
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 4)
+    share = min(share, os.cpu_count() or share)
+    workers = max(1, share - 2)  # the reference's "auto" rule: cores - 2 (config/train_config.py:35-38)
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(workers) as pool:
+        res = pool.map(_cpu_worker, [(workload, 1000 + i, budget_s) for i in range(workers)])
+    sims = sum(r[0] for r in res)
+    wall = max(r[2] for r in res)
+    game, n, nsims, _, _ = WORKLOADS[workload]
+    return {"value": sims / wall, "unit": "sims/s", "cores": workers, "kind": "port",
+            "sample": f"{workers} single-thread workers x {budget_s:.0f} s of {workload} self-play "
+                      f"({nsims} sims/move, same net on torch-CPU, batch 1) on the CPU oracle",
+            "per_core": sims / wall / workers}
+
+
+# ------------------------------------------------------------------------------ GPU bench -------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="gomoku15", choices=sorted(WORKLOADS))
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--sims", type=int, default=0)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--evaluator", default="model", choices=["model", "hash"])
+    ap.add_argument("--preroll", type=int, default=96, help="cheap 2-sim move rounds that stagger game ages")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.cpu_baseline_seconds > 0:
+        cpu = cpu_baseline(args.workload, args.cpu_baseline_seconds)  # before anything touches the GPU
+
+    import torch
+    import torch.distributed as dist
+
+    from alphazero_amd import Engine
+    from alphazero_amd.arena import SelfPlayRunner, reference_tao
+    from alphazero_amd.samples import HostSampleRing, WeightPublisher
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    game, n, sims, slots, _ = WORKLOADS[args.workload]
+    sims = args.sims or sims
+    slots = args.slots or slots
+    tdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    model = make_model(args.workload).to(dev)
+    if tdtype != torch.float32:
+        model = model.to(tdtype)
+    model = model.to(memory_format=torch.channels_last)
+    publisher = WeightPublisher(model, src=0)
+
+    eng = Engine(game, slots, sims, board_size=n, nn_dtype=tdtype, device=dev)
+    d = eng.dims
+    run = SelfPlayRunner(eng, model, sims, channels_last=True)
+    if args.evaluator == "hash":  # tree kernels alone (no network)
+        run.evaluate = lambda: eng.eval_hash(run.nn_input, run.logits, run.values, 6.0)
+    ring = HostSampleRing(max(4 * slots, 65536), (d.nn_channels, d.height, d.width), d.n_action)
+    esize = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}[tdtype]
+
+    games_started = slots
+    inv_tao_h = torch.tensor([1.0 / reference_tao(0)] * slots, dtype=torch.float32)
+    inv_tao = inv_tao_h.to(dev)
+    finished_games = 0
+    finished_plies = 0
+
+    def collect(done):
+        """emit + D2H the samples of the games that just ended, restart their slots"""
+        nonlocal games_started, finished_games, finished_plies
+        done_h = done.cpu()
+        idx = torch.nonzero(done_h).reshape(-1)
+        if idx.numel() == 0:
+            return
+        plies, _, _, _ = eng.game_info()
+        plies_h = plies.cpu()[idx]
+        states, pis, zs, _ = eng.emit_samples(idx.to(torch.int32), plies_h)
+        ring.put_batch(states, pis, zs)
+        finished_games += int(idx.numel())
+        finished_plies += int(plies_h.sum())
+        for s in idx.tolist():  # per-slot temperature schedule restarts with the new game
+            inv_tao_h[s] = 1.0 / reference_tao(games_started // slots)
+            games_started += 1
+        inv_tao.copy_(inv_tao_h, non_blocking=True)
+        eng.reset_games(done)
+
+    # --- pre-roll: stagger game ages so that games finish at a steady rate during the timed steps
+    if args.preroll > 0:
+        run.num_sims = 2
+        R = args.preroll
+        ar = torch.arange(slots, device=dev)
+        for r in range(R):
+            _, done = run.move_round(inv_tao)
+            eng.reset_games(((ar % R == r) | (done != 0)).to(torch.uint8))
+        run.num_sims = sims
+        eng.check()
+
+    ev_sel, ev_exp, ev_nn = [], [], []
+
+    def timed_round():
+        """run.move_round with HIP events around each tree kernel and each network forward"""
+        noise = run.draw_noise()
+        eng.begin_search()
+        for _ in range(sims):
+            a, b, c, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+            a.record()
+            eng.select_gather(run.nn_input)
+            b.record()
+            run.evaluate()
+            c.record()
+            eng.expand_backup(run.logits, run.values, noise)
+            e2.record()
+            ev_sel.append((a, b)); ev_nn.append((b, c)); ev_exp.append((c, e2))
+        run.draw_expo()
+        eng.play_moves(inv_tao, run.expo, None, run.actions, run.done)
+        return run.done
+
+    def step(timed: bool):
+        publisher.publish()  # learner -> self-play weight push (RCCL broadcast; no-op at N = 1)
+        done = timed_round() if timed else run.move_round(inv_tao)[1]
+        collect(done)
+
+    for _ in range(args.warmup):
+        step(False)
+    eng.check()
+    eng.reset_stats()
+    finished_games = finished_plies = 0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.check()
+    st = eng.read_stats()
+
+    tt = torch.tensor([elapsed, float(st["sims"]), float(finished_games), float(finished_plies)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+    total_sims, total_games, total_plies = float(tt[1]), float(tt[2]), float(tt[3])
+
+    if rank == 0:
+        def mean_ms(pairs):
+            return sum(a.elapsed_time(b) for a, b in pairs) / max(len(pairs), 1)
+
+        nin = d.nn_channels * d.height * d.width
+        launches = max(len(ev_sel), 1)
+        sel_ms, exp_ms, nn_ms = mean_ms(ev_sel), mean_ms(ev_exp), mean_ms(ev_nn)
+        # algorithmic bytes (DESIGN.md "bytes per simulation"): child record = P f32 + N i32 + Q f64 + act u16
+        sel_bytes = (18.0 * st["sum_children"] + 22.0 * st["sum_depth"] + st["evals"] * (nin * esize + 4.0 * d.state_words)
+                     + st["sims"] * (16.0 + 36.0 * d.state_words)) / launches
+        exp_bytes = (st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 22.0 * st["expanded_edges"]
+                     + 26.0 * st["sum_depth"] + 28.0 * st["sims"]) / launches
+        dom = ("k_select_gather", sel_bytes, sel_ms) if sel_ms >= exp_ms else ("k_expand_backup", exp_bytes, exp_ms)
+        achieved = dom[1] / (dom[2] * 1e-3) / 1e9 if dom[2] > 0 else 0.0
+        out = {
+            "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {sims} sims/move, {slots} concurrent games per GPU, "
+                                   f"evaluator={args.evaluator}, one step = one self-play move of every game",
+                       "slots_per_gpu": slots, "sims_per_move": sims, "parallelism": f"games sharded x{world}, no data-path collective"},
+            "games_per_sec": total_games / elapsed, "plies_per_sec": slots * world * args.steps / elapsed,
+            "mean_plies_per_finished_game": (total_plies / total_games) if total_games else None,
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None, "bytes_per_launch": dom[1], "ms_per_launch": dom[2]},
+            "tree_kernels": {"k_select_gather": {"ms": sel_ms, "bytes": sel_bytes, "GBps": sel_bytes / max(sel_ms, 1e-9) / 1e6},
+                             "k_expand_backup": {"ms": exp_ms, "bytes": exp_bytes, "GBps": exp_bytes / max(exp_ms, 1e-9) / 1e6},
+                             "mean_depth": st["sum_depth"] / max(st["sims"], 1),
+                             "mean_children_per_level": st["sum_children"] / max(st["sum_depth"], 1),
+                             "evals_per_sim": st["evals"] / max(st["sims"], 1)},
+            "cpu_baseline": cpu,
+        }
+        if args.evaluator == "model" and hasattr(model, "flops_per_eval"):
+            fl = model.flops_per_eval() * slots
+            out["nn_eval"] = {"bound": "mfma", "ms_per_batch": nn_ms, "achieved": fl / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
+                              "peak": 2500.0, "unit": "TFLOP/s", "frac": (fl / (nn_ms * 1e-3) / 1e12 / 2500.0) if nn_ms else 0.0,
+                              "flops_per_eval": model.flops_per_eval(), "share_of_step": nn_ms / max(nn_ms + sel_ms + exp_ms, 1e-9)}
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
