@@ -67,3 +67,8 @@ class WeightPublisher:
                 t.copy_(self.flat[off:off + t.numel()].view_as(t))
                 off += t.numel()
         return self.flat.numel() * 4
+
+
+def games_for_rank(n_games: int, rank: int, world: int) -> range:
+    """Game ids owned by a rank: game g lives on rank g % world; no game ever moves."""
+    return range(rank, n_games, world)

@@ -1,0 +1,120 @@
+"""GPU tests of the drop-in boundary: ChessArena (training/self_play.py surface) and MCTS.search
+(core/MCTS_alphazero.py:128) served by the HIP engine, against the CPU oracle driven with the same
+seeded randomness and the same (integer-exact) network."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from .helpers import HashNet, ListPool
+
+pytestmark = pytest.mark.gpu
+
+GAMES = [("tictactoe", 0, 3, 9, 40), ("dab", 1, 3, 24, 30), ("gomoku9", 2, 9, 81, 24)]
+
+
+def _game_cls(name):
+    from alphazero_amd import games
+
+    return {"tictactoe": games.TicTacToeGame, "dab": games.DotsAndBoxesGame, "gomoku9": games.Gomoku9Game}[name]
+
+
+def _reference_draws(seed, A, plies):
+    """the draws a seeded reference game makes, in its order: Dirichlet then multinomial's exponentials"""
+    from torch.distributions import Dirichlet
+
+    torch.manual_seed(seed)
+    noise, expo = [], []
+    for _ in range(plies):
+        noise.append(Dirichlet(torch.ones(1, A) * 0.3).sample().reshape(-1).numpy())
+        expo.append(torch.empty(1, A).exponential_(1).reshape(-1).numpy())
+    return np.array(noise, np.float32), np.array(expo, np.float32)
+
+
+@pytest.mark.parametrize("name,game,n,A,sims", GAMES)
+@pytest.mark.parametrize("tao", [1.0, 0.5])
+def test_arena_self_play_replays_like_the_reference(oracle, name, game, n, A, sims, tao):
+    from alphazero_amd.arena import ChessArena
+
+    seed = 1234
+    max_plies = {0: 9, 1: 24, 2: 81}[game]
+    noise, expo = _reference_draws(seed, A, max_plies)
+    arena = ChessArena(functools.partial(HashNet, A, 5.0), _game_cls(name), torch.device("cuda:0"), num_simulation=sims)
+    assert not arena.model.training
+    pool = ListPool()
+    torch.manual_seed(seed)
+    arena.self_play(tao, pool)
+    d = oracle.dims(game, n)
+    ev = oracle.torch_eval(HashNet(A, 5.0), (d["cin"], d["H"], d["W"]))
+    r = oracle.self_play(game, n, sims, tao, expo, ev, noise=noise, max_plies=max_plies)
+    assert len(pool.items) == r["plies"]
+    for k, (st, pi, z) in enumerate(pool.items):  # put order: last position first
+        t = r["plies"] - 1 - k
+        assert st.shape == (1, d["cin"], d["H"], d["W"]) and st.dtype == torch.float32 and st.device.type == "cpu"
+        assert pi.shape == (1, A) and pi.dtype == torch.float32 and z.shape == (1,) and z.dtype == torch.float32
+        assert np.array_equal(st.numpy().reshape(-1), r["nn_states"][t])
+        assert np.array_equal(pi.numpy().reshape(-1), r["pis"][t])
+        assert float(z[0]) == float(r["z"][t])
+
+
+@pytest.mark.parametrize("name,game,n,A,sims", GAMES)
+def test_mcts_search_adapter(oracle, name, game, n, A, sims):
+    from alphazero_amd.mcts import MCTS
+    from torch.distributions import Dirichlet
+
+    cls = _game_cls(name)
+    g = cls()
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        legal = np.nonzero(g.get_legal_mask().numpy().reshape(-1))[0]
+        g.step(int(rng.choice(legal)))
+    model = HashNet(A, 5.0).cuda()
+    mcts = MCTS(cls)
+    d = oracle.dims(game, n)
+    ev = oracle.torch_eval(HashNet(A, 5.0), (d["cin"], d["H"], d["W"]))
+    for use_dir in (True, False):
+        torch.manual_seed(77)
+        pi = mcts.search(model, g.get_state(), g.get_player(), history_state=g.get_history(), num_simulation=sims,
+                         use_Dirichlet=use_dir)
+        assert pi.shape == (1, A) and pi.dtype == torch.float32
+        torch.manual_seed(77)
+        noise = Dirichlet(torch.ones(1, A) * 0.3).sample().numpy().reshape(-1) if use_dir else None
+        r = oracle.search(game, n, g.get_state().numpy(), g.get_player(), g.get_history().numpy(), sims, ev, noise=noise)
+        assert np.array_equal(pi.cpu().numpy().reshape(-1), r["pi"])
+    with pytest.raises(ValueError):
+        mcts.search(model, g.get_state(), g.get_player())
+
+
+def test_self_play_many_recycles_slots_and_fills_the_pool():
+    from alphazero_amd.arena import ChessArena, reference_tao
+    from alphazero_amd.games import TicTacToeGame
+    from alphazero_amd.nets import TicTacToeNet
+
+    torch.manual_seed(0)
+    arena = ChessArena(TicTacToeNet, TicTacToeGame, torch.device("cuda:0"), n_slots=16, num_simulation=30)
+    pool = ListPool()
+    out = arena.self_play_many(50, reference_tao, pool)  # 50 games through 16 slots
+    assert out["games"] == 50 and out["samples"] == len(pool.items) and 5 * 50 <= len(pool.items) <= 9 * 50
+    zs = torch.cat([e[2] for e in pool.items])
+    assert set(zs.tolist()) <= {-1.0, 0.0, 1.0}
+    pis = torch.cat([e[1] for e in pool.items])
+    assert torch.allclose(pis.sum(1), torch.ones(len(pool.items)), atol=1e-5)
+    st = torch.cat([e[0] for e in pool.items])
+    assert st.shape[1:] == (9, 3, 3) and set(st.unique().tolist()) <= {-1.0, 0.0, 1.0}
+    # the newest history plane of a sample holds as many stones as plies were played before it; the
+    # player plane is +1 exactly when that count is even
+    stones = st[:, 7].abs().sum((1, 2))
+    assert torch.equal((stones % 2 == 0), (st[:, 8, 0, 0] == 1))
+    assert arena.games_played == 50
+
+    class BatchPool:
+        def __init__(self):
+            self.n = 0
+
+        def put_batch(self, s, p, z):
+            assert s.shape[0] == p.shape[0] == z.shape[0] and s.shape[1:] == (9, 3, 3)
+            self.n += s.shape[0]
+
+    bp = BatchPool()
+    assert arena.self_play_many(20, 1.0, bp)["samples"] == bp.n

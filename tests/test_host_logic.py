@@ -1,0 +1,136 @@
+"""CPU tests of the host side: the games mirror against the reference's rule fixtures, the HashNet
+helper against the oracle's hash evaluator, network contracts, sample ring, and the N>1 weight
+publish over gloo (world_size 2)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from .conftest import GOLDEN, ROOT
+from .helpers import HashNet
+
+from alphazero_amd import games, nets
+from alphazero_amd.arena import reference_tao, resolve_game
+from alphazero_amd.samples import HostSampleRing, games_for_rank
+
+MIRROR = [("tictactoe", games.TicTacToeGame), ("dab", games.DotsAndBoxesGame), ("gomoku15", games.GomokuGame),
+          ("gomoku9", games.Gomoku9Game)]
+
+
+@pytest.mark.parametrize("name,cls", MIRROR)
+def test_games_mirror_matches_reference_rules(name, cls):
+    z = np.load(os.path.join(GOLDEN, f"rules_{name}.npz"))
+    n_games = int(z["n_games"])
+    step = 1 if name != "gomoku15" else 2  # the O(N^2) winner scan is slow in torch; half the games suffice
+    for g in range(0, n_games, step):
+        s, player = cls.initial_state(), 1
+        assert np.array_equal(cls.legal_action_mask(s).numpy().reshape(-1), z[f"g{g}_mask0"])
+        for k, a in enumerate(z[f"g{g}_actions"]):
+            s, player = cls.next_state(s, int(a), player)
+            assert np.array_equal(s.numpy().reshape(-1).astype(np.int8), z[f"g{g}_states"][k])
+            assert player == z[f"g{g}_next_players"][k]
+            assert np.array_equal(cls.legal_action_mask(s).numpy().reshape(-1), z[f"g{g}_masks"][k])
+            assert bool(cls.is_terminal(s)) == bool(z[f"g{g}_terminal"][k])
+            w = cls._get_winner(s)
+            assert (0 if w is None else w) == z[f"g{g}_winner"][k]
+    s, _ = cls.next_state(cls.initial_state(), 0, 1)
+    for a in (0, -1, 10 ** 6):
+        with pytest.raises(ValueError):
+            cls.next_state(s, a, -1)
+
+
+def test_game_instance_history_and_player_channel():
+    g = games.DotsAndBoxesGame()
+    assert g.get_history().shape == (24, 4, 4) and g.get_player() == 1
+    g.step(0)
+    h = g.get_history()
+    assert torch.equal(h[21:], g.get_state()) and float(h[:21].abs().sum()) == 0
+    t = games.TicTacToeGame()
+    assert t.get_history().shape == (8, 3, 3)
+    pc = games.BaseGame.get_player_channel(t.get_state(), -1)
+    assert pc.shape == (1, 3, 3) and pc.dtype == torch.int64 and int(pc[0, 0, 0]) == -1
+    assert resolve_game(games.Gomoku9Game) == (2, 9) and resolve_game(games.TicTacToeGame) == (0, 3)
+
+
+def test_hashnet_equals_oracle_hash(oracle):
+    import ctypes as C
+
+    rng = np.random.default_rng(0)
+    x = rng.integers(-1, 2, size=(5, 9, 9, 9)).astype(np.float32)
+    net = HashNet(81, 5.0)
+    p, v = net(torch.from_numpy(x))
+    fn, ctx, _keep = oracle.hash_eval(5.0)
+    for b in range(5):
+        lg = np.zeros(81, np.float32)
+        val = C.c_float()
+        row = np.ascontiguousarray(x[b].reshape(-1))
+        fn(ctx, row.ctypes.data_as(C.POINTER(C.c_float)), row.size, lg.ctypes.data_as(C.POINTER(C.c_float)), 81,
+           C.byref(val))
+        assert np.array_equal(p[b].numpy(), lg) and float(v[b, 0]) == val.value
+
+
+def test_net_contracts_and_sizes():
+    # parameter counts of the reference's example nets
+    cases = [(nets.TicTacToeNet(), (2, 9, 3, 3), 9, 154186), (nets.DotsAndBoxesNet(), (2, 25, 4, 4), 24, 53532),
+             (nets.GomokuNet(), (2, 9, 15, 15), 225, 233257), (nets.GomokuNet(9), (2, 9, 9, 9), 81, None)]
+    for net, shape, A, nparam in cases:
+        net.eval()
+        p, v = net(torch.zeros(shape))
+        assert p.shape == (2, A) and v.shape == (2, 1) and float(v.abs().max()) <= 1.0
+        if nparam:
+            assert sum(q.numel() for q in net.parameters()) == nparam
+    keys = set(nets.GomokuNet().state_dict())
+    for k in ("_shared_layers.0.weight", "_shared_layers.3._conv1.weight", "_shared_layers.4._bn2.running_var",
+              "_policy_head.4.weight", "_value_head.6.bias"):
+        assert k in keys  # the reference's checkpoint keys (examples/gomoku/model.py)
+    assert abs(nets.GomokuNet().flops_per_eval() - 68.9e6) < 0.2e6
+
+
+def test_tao_schedule_and_sharding():
+    assert reference_tao(0) == 1.0 and abs(reference_tao(10) - 0.997 ** 10) < 1e-12 and reference_tao(10 ** 4) == 0.1
+    owned = [list(games_for_rank(10, r, 4)) for r in range(4)]
+    assert sorted(sum(owned, [])) == list(range(10)) and owned[1] == [1, 5, 9]
+
+
+def test_host_sample_ring_wraps_in_put_order():
+    ring = HostSampleRing(5, (2, 1, 1), 3, pin=False)
+    for start in (0, 4):
+        n = 4
+        st = torch.arange(start, start + n).float().view(n, 1).repeat(1, 2)
+        ring.put_batch(st, torch.ones(n, 3) * st[:, :1], st[:, 0])
+    assert ring.size() == 5 and ring.total == 8 and ring.write_idx == 3
+    assert ring.values.view(-1).tolist() == [5.0, 6.0, 7.0, 3.0, 4.0]
+    assert ring.states.shape == (5, 1, 2, 1, 1) and ring.priors.shape == (5, 1, 3)
+
+
+_WORKER = r"""
+import sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+from alphazero_amd import nets
+from alphazero_amd.samples import WeightPublisher
+rank, port = int(sys.argv[1]), sys.argv[2]
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+torch.manual_seed(rank)                      # different weights on each rank before the publish
+m = nets.DotsAndBoxesNet()
+want = nets.DotsAndBoxesNet.__new__(nets.DotsAndBoxesNet)
+torch.manual_seed(0); ref = nets.DotsAndBoxesNet()
+n = WeightPublisher(m, src=0).publish()
+same = all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), ref.state_dict().values()))
+flag = torch.tensor([1.0 if same else 0.0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if (flag.item() == 1.0 and n == 4 * 53532) else 3)
+"""
+
+
+def test_weight_publish_world_size_2_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(port), ROOT]) for r in range(2)]
+    assert [p.wait(timeout=120) for p in procs] == [0, 0]
