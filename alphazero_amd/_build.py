@@ -5,8 +5,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, "csrc", "az_engine.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "az_games.cuh"),
+SRCS = [os.path.join(_HERE, "csrc", "az_engine.hip"), os.path.join(_HERE, "csrc", "az_tower.hip")]
+DEPS = [*SRCS, os.path.join(_HERE, "csrc", "az_games.cuh"),
         os.path.join(os.path.dirname(_HERE), "include", "az_engine.h")]
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libaz_engine.so")
@@ -29,7 +29,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, "-o", LIB, SRC]
+    cmd = [hipcc, *FLAGS, "-o", LIB, *SRCS]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

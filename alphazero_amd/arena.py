@@ -57,7 +57,8 @@ class SelfPlayRunner:
     """One move of search + play for every active slot of an engine; used by ChessArena and bench.py."""
 
     def __init__(self, engine: Engine, model: torch.nn.Module, num_sims: int, alpha: float = ALPHA,
-                 use_dirichlet: bool = True, reference_rng: bool = False, channels_last: bool = False):
+                 use_dirichlet: bool = True, reference_rng: bool = False, channels_last: bool = False,
+                 fused: bool = False):
         if num_sims > engine.max_sims:
             raise EngineError("num_sims exceeds the engine's max_sims")
         self.e, self.model, self.num_sims = engine, model, num_sims
@@ -76,9 +77,20 @@ class SelfPlayRunner:
         p = next(model.parameters(), None)
         self.model_device = p.device if p is not None else torch.device("cpu")
         self.model_dtype = p.dtype if p is not None else torch.float32
+        self.fused = None
+        if fused:  # hand-written MFMA conv tower (csrc/az_tower.hip) instead of the module's own forward
+            from .fused import FusedTowerEvaluator
+
+            if engine.nn_dtype != torch.bfloat16:
+                raise EngineError("the fused evaluator reads a bf16 batch: create the engine with nn_dtype=torch.bfloat16")
+            self.fused = FusedTowerEvaluator(model)
 
     # one model forward on the gathered batch -> self.logits / self.values (f32, engine device)
     def evaluate(self) -> None:
+        if self.fused is not None:
+            _, v = self.fused(self.nn_input, logits_out=self.logits)
+            self.values.copy_(v.view(-1), non_blocking=True)
+            return
         x = self.nn_input
         if x.device != self.model_device or x.dtype != self.model_dtype:
             x = x.to(device=self.model_device, dtype=self.model_dtype)

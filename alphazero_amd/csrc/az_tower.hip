@@ -1,0 +1,267 @@
+// az_tower.hip -- fused residual conv tower (policy/value trunk + head 1x1 convs) for MI355X.
+//
+// No counterpart in the reference beyond the model contract (nn_models/base.py:17-19): it evaluates
+// the GomokuModel family of examples/gomoku/model.py:41-90 -- conv3x3(9->64)+BN+ReLU, `blocks` residual
+// blocks of two conv3x3(64->64)+BN, then the 1x1 head convs+BN+ReLU -- in ONE kernel, with the board's
+// activations resident in LDS for the whole tower and every conv an implicit GEMM on bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16, f32 accumulate).  BatchNorm (eval mode) is folded into the conv weights
+// and a per-channel bias by the host (alphazero_amd/fused.py).  The two small head Linear layers stay
+// in PyTorch (hipBLASLt).  C ABI at the bottom; declared in include/az_engine.h.
+//
+// Mapping (one workgroup = 4 waves = BPW boards):
+//   LDS act[pos][64 ch] bf16, pos on a zero-padded (N+2)^2 grid, 128 B per position, the eight 16-byte
+//   channel chunks of a position XOR-swizzled with (pos>>1)&7 so that the 16 lanes of a ds_read_b128
+//   group hit 16 different bank quads.
+//   GEMM orientation: D[co][pos] = sum_k W[co][k] * X[k][pos], k = (tap, ci).  A = weights (rows = out
+//   channels), B = activations (cols = positions): the accumulator then holds, per lane, ONE position
+//   and 4-channel runs, which pack into 8-byte LDS stores in the epilogue.
+//   8 position tiles of 32 (2 per wave) x 2 channel tiles of 32: 4 accumulators (64 VGPRs) per wave.
+//   Per tap the 64x64 weight slice (8 KiB) is staged global -> registers -> LDS, double buffered, and
+//   shared by the 4 waves; the layer is computed in place (outputs stay in accumulators until every
+//   wave has finished reading the input, then overwrite it); the residual is kept in registers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/az_engine.h"
+
+namespace aztower {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int CH = 64;          // trunk width
+constexpr int TAP_BYTES = 8192; // one tap of a 64->64 layer: [ks 4][half 2][co 64][8] bf16
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ int act_addr(int p, int chunk) { return p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4); }
+
+template <int N, int BPW>
+struct Geo {
+  static constexpr int P = N + 2, NPOS = P * P, NV = N * N, NVT = BPW * NV;
+  static constexpr int ACT_BYTES = BPW * NPOS * 128;
+  static_assert(NVT <= 256, "8 position tiles of 32");
+};
+
+// one conv layer, in registers: acc[pt][ct] += W * X.  KS = 16-channel k-steps per tap (1 or 4).
+template <int KS, int P>
+__device__ __forceinline__ void conv_layer(const char *act, char *wbuf, const char *wg, int tid, int lane,
+                                           const int (&pp)[2], f32x16 (&acc)[2][2]) {
+  constexpr int TB = KS * 2048;  // bytes per tap: 2 KiB (stem, threads 0..127 move it) or 8 KiB (2 x 16 B per thread)
+  const int h = lane >> 5, r = lane & 31;
+  const bool mover = (KS == 4) || tid < 128;
+  const int o0 = tid * 16, o1 = 4096 + tid * 16;
+  // tap 0 -> buffer 0
+  if (mover) *(uint4 *)(wbuf + o0) = *(const uint4 *)(wg + o0);
+  if (KS == 4) *(uint4 *)(wbuf + o1) = *(const uint4 *)(wg + o1);
+  __syncthreads();
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    uint4 s0 = make_uint4(0, 0, 0, 0), s1 = make_uint4(0, 0, 0, 0);
+    const char *wgn = wg + (tap < 8 ? tap + 1 : 8) * TB;  // tap 8 re-reads its own slice (discarded)
+    if (mover) s0 = *(const uint4 *)(wgn + o0);
+    if (KS == 4) s1 = *(const uint4 *)(wgn + o1);
+    const char *wc = wbuf + (tap & 1) * TAP_BYTES;
+    const int d = (tap / 3 - 1) * P + (tap % 3 - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int chunk = ks * 2 + h;
+      const bf16x8 a0 = *(const bf16x8 *)(wc + chunk * 1024 + r * 16);
+      const bf16x8 a1 = *(const bf16x8 *)(wc + chunk * 1024 + 512 + r * 16);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const bf16x8 b = *(const bf16x8 *)(act + act_addr(pp[pt] + d, chunk));
+        acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[pt][0], 0, 0, 0);
+        acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[pt][1], 0, 0, 0);
+      }
+    }
+    char *wn = wbuf + ((tap + 1) & 1) * TAP_BYTES;  // after tap 8 this refills buffer 1, which nobody reads again
+    if (mover) *(uint4 *)(wn + o0) = s0;
+    if (KS == 4) *(uint4 *)(wn + o1) = s1;
+    __syncthreads();  // after tap 8: every wave has finished reading act -> the epilogue may overwrite it
+  }
+}
+
+// bias (+ residual) + ReLU, bf16, written back in place
+template <bool RES>
+__device__ __forceinline__ void epilogue(char *act, const float *bias, int lane, const int (&pp)[2], const bool (&ok)[2],
+                                         const f32x16 (&acc)[2][2], const uint2 (&res)[2][2][4]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    if (!ok[pt]) continue;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bv = *(const float4 *)(bias + ct * 32 + q * 8 + h * 4);
+        float v0 = acc[pt][ct][4 * q + 0] + bv.x, v1 = acc[pt][ct][4 * q + 1] + bv.y;
+        float v2 = acc[pt][ct][4 * q + 2] + bv.z, v3 = acc[pt][ct][4 * q + 3] + bv.w;
+        if (RES) {
+          const uint2 rr = res[pt][ct][q];
+          v0 += bf_lo(rr.x); v1 += bf_hi(rr.x); v2 += bf_lo(rr.y); v3 += bf_hi(rr.y);
+        }
+        v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
+        *(uint2 *)(act + act_addr(pp[pt], ct * 4 + q) + 8 * h) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+      }
+  }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+}
+
+// x: (G, 9, N, N) bf16.  w0: [9][1][2][64][8] bf16 (first conv, 9 input channels padded to 16).
+// wl: [L][9][4][2][64][8] bf16.  bias: [1+L][64] f32.  headw: [3][64] f32 (policy, value0, value1),
+// headb: [3].  pfeat: (G, NV) f32, vfeat: (G, 2, NV) f32 (= the inputs of the heads' Linear layers).
+template <int N, int BPW>
+__global__ __launch_bounds__(256, 2) void k_tower(const uint16_t *__restrict__ x, int G, const char *__restrict__ w0,
+                                               const char *__restrict__ wl, const float *__restrict__ bias, int L,
+                                               const float *__restrict__ headw, const float *__restrict__ headb,
+                                               float *__restrict__ pfeat, float *__restrict__ vfeat) {
+  using Q = Geo<N, BPW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *act = smem;
+  char *wbuf = smem + Q::ACT_BYTES;
+  float *hw = (float *)(wbuf + 2 * TAP_BYTES);  // 3*64 + 3 floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int i = tid; i < Q::ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // halos stay zero
+  for (int i = tid; i < 3 * CH + 3; i += 256) hw[i] = i < 3 * CH ? headw[i] : headb[i - 3 * CH];
+
+  // this lane's two positions (B-operand column / accumulator column): tile = 2*wave + pt
+  int pp[2];
+  bool ok[2];
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int m = (2 * wave + pt) * 32 + (lane & 31);
+    ok[pt] = m < Q::NVT;
+    const int mm = ok[pt] ? m : 0, b = mm / Q::NV, cell = mm % Q::NV;
+    pp[pt] = b * Q::NPOS + (cell / N + 1) * Q::P + (cell % N + 1);
+  }
+  __syncthreads();
+
+  const int ngroups = (G + BPW - 1) / BPW;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // ---- input: NCHW bf16 rows -> act[pos][0..15] (channels 9..15 zero)
+    for (int m = tid; m < Q::NVT; m += 256) {
+      const int b = m / Q::NV, cell = m % Q::NV, g = grp * BPW + b;
+      uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (g < G) {
+        const uint16_t *xr = x + (size_t)g * 9 * Q::NV + cell;
+#pragma unroll
+        for (int ch = 0; ch < 9; ++ch) c[ch >> 1] |= (uint32_t)xr[ch * Q::NV] << ((ch & 1) * 16);
+      }
+      const int p = b * Q::NPOS + (cell / N + 1) * Q::P + (cell % N + 1);
+      *(uint4 *)(act + act_addr(p, 0)) = make_uint4(c[0], c[1], c[2], c[3]);
+      *(uint4 *)(act + act_addr(p, 1)) = make_uint4(c[4], c[5], c[6], c[7]);
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+    uint2 res[2][2][4];
+    // ---- stem
+    zero_acc(acc);
+    conv_layer<1, Q::P>(act, wbuf, w0, tid, lane, pp, acc);
+    epilogue<false>(act, bias, lane, pp, ok, acc, res);
+    __syncthreads();
+    // ---- residual blocks
+    for (int l = 0; l < L; l += 2) {
+      const int h = lane >> 5;
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pp[pt], ct * 4 + q) + 8 * h);
+      zero_acc(acc);
+      conv_layer<4, Q::P>(act, wbuf, wl + (size_t)l * 9 * TAP_BYTES, tid, lane, pp, acc);
+      epilogue<false>(act, bias + (1 + l) * CH, lane, pp, ok, acc, res);
+      __syncthreads();
+      zero_acc(acc);
+      conv_layer<4, Q::P>(act, wbuf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid, lane, pp, acc);
+      epilogue<true>(act, bias + (2 + l) * CH, lane, pp, ok, acc, res);
+      __syncthreads();
+    }
+    // ---- heads: 1x1 convs (+folded BN) + ReLU, one position per thread
+    for (int m = tid; m < Q::NVT; m += 256) {
+      const int b = m / Q::NV, cell = m % Q::NV, g = grp * BPW + b;
+      if (g >= G) continue;
+      const int p = b * Q::NPOS + (cell / N + 1) * Q::P + (cell % N + 1);
+      float s0 = hw[3 * CH + 0], s1 = hw[3 * CH + 1], s2 = hw[3 * CH + 2];
+#pragma unroll
+      for (int chunk = 0; chunk < 8; ++chunk) {
+        const uint4 u = *(const uint4 *)(act + act_addr(p, chunk));
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo = bf_lo(w[k]), hi = bf_hi(w[k]);
+          const int c = chunk * 8 + 2 * k;
+          s0 += lo * hw[c] + hi * hw[c + 1];
+          s1 += lo * hw[CH + c] + hi * hw[CH + c + 1];
+          s2 += lo * hw[2 * CH + c] + hi * hw[2 * CH + c + 1];
+        }
+      }
+      pfeat[(size_t)g * Q::NV + cell] = fmaxf(s0, 0.0f);
+      vfeat[((size_t)g * 2 + 0) * Q::NV + cell] = fmaxf(s1, 0.0f);
+      vfeat[((size_t)g * 2 + 1) * Q::NV + cell] = fmaxf(s2, 0.0f);
+    }
+    __syncthreads();  // heads done reading before the next group's input lands
+  }
+}
+
+}  // namespace aztower
+
+static std::string g_tower_err;
+
+extern "C" {
+
+const char *az_tower_last_error(void) { return g_tower_err.c_str(); }
+
+int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
+                     const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
+                     const float *headb_dev, float *pfeat_dev, float *vfeat_dev, void *stream) {
+  using namespace aztower;
+  if (!x_bf16_dev || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !pfeat_dev || !vfeat_dev ||
+      (n_conv_layers > 0 && !wl_dev)) { g_tower_err = "null argument"; return AZ_EINVAL; }
+  if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1)) { g_tower_err = "n_boards >= 1, even n_conv_layers"; return AZ_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t err;
+  if (board_size == 15) {
+    constexpr int BPW = 1;
+    const size_t lds = Geo<15, BPW>::ACT_BYTES + 2 * TAP_BYTES + 1024;
+    static bool attr15 = false;
+    if (!attr15) { (void)hipFuncSetAttribute((const void *)k_tower<15, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr15 = true; }
+    const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 512 ? groups : 512;
+    hipLaunchKernelGGL((k_tower<15, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, n_boards, (const char *)w0_dev,
+                       (const char *)wl_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
+  } else if (board_size == 9) {
+    constexpr int BPW = 3;
+    const size_t lds = Geo<9, BPW>::ACT_BYTES + 2 * TAP_BYTES + 1024;
+    static bool attr9 = false;
+    if (!attr9) { (void)hipFuncSetAttribute((const void *)k_tower<9, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr9 = true; }
+    const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 512 ? groups : 512;
+    hipLaunchKernelGGL((k_tower<9, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, n_boards, (const char *)w0_dev,
+                       (const char *)wl_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
+  } else {
+    g_tower_err = "board_size must be 9 or 15";
+    return AZ_EINVAL;
+  }
+  err = hipGetLastError();
+  if (err != hipSuccess) { g_tower_err = std::string("k_tower launch: ") + hipGetErrorString(err); return AZ_EHIP; }
+  return AZ_OK;
+}
+
+}  // extern "C"

@@ -40,7 +40,7 @@ class AzStats(C.Structure):
 EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check", "az_reset_games",
            "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_root_policy",
            "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
-           "az_reset_stats", "az_eval_hash"]
+           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error"]
 
 _lib = None
 
@@ -76,8 +76,11 @@ def load_library() -> C.CDLL:
     lib.az_read_stats.argtypes = [vp, C.POINTER(AzStats), vp]
     lib.az_reset_stats.argtypes = [vp, vp]
     lib.az_eval_hash.argtypes = [vp, vp, C.c_float, vp, vp, vp]
+    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.az_tower_last_error.argtypes = []
+    lib.az_tower_last_error.restype = C.c_char_p
     for name in EXPORTS:
-        if name != "az_last_error":
+        if name not in ("az_last_error", "az_tower_last_error"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

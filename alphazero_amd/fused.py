@@ -1,0 +1,108 @@
+"""Fused evaluator for GomokuModel-family networks (examples/gomoku/model.py:41-90 and
+alphazero_amd.nets.GomokuNet): the conv tower runs as ONE hand-written bf16 MFMA kernel
+(csrc/az_tower.hip, activations resident in LDS); eval-mode BatchNorm is folded into the conv weights
+here; the heads' small Linear layers stay in PyTorch.  Same contract as the module it wraps:
+``(B, 9, N, N) -> (logits (B, N*N) f32, value (B, 1) f32)``.  Call ``refresh()`` after the module's
+weights change (load_state_dict / weight publish)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .engine import EngineError, load_library
+
+
+def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    w = conv.weight.detach().float()
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    b = bn.bias.detach().float() - bn.running_mean.detach().float() * s
+    if conv.bias is not None:
+        b = b + conv.bias.detach().float() * s
+    return w * s.view(-1, 1, 1, 1), b
+
+
+def _pack3x3(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
+    """(co=64, ci, 3, 3) f32 -> [tap 9][k-step][k-half 2][co 64][8] bf16"""
+    co, ci = w.shape[0], w.shape[1]
+    if ci < cin_pad:
+        w = torch.cat([w, w.new_zeros(co, cin_pad - ci, 3, 3)], 1)
+    t = w.permute(2, 3, 1, 0).reshape(9, cin_pad // 16, 2, 8, co)  # tap, ks, half, j, co
+    return t.permute(0, 1, 2, 4, 3).contiguous().to(torch.bfloat16)
+
+
+class FusedTowerEvaluator:
+    @staticmethod
+    def supports(model: nn.Module) -> bool:
+        try:
+            sl = model._shared_layers
+            stem, blocks = sl[0], [m for m in list(sl)[3:]]
+            ok = isinstance(stem, nn.Conv2d) and stem.in_channels == 9 and stem.out_channels == 64 and \
+                stem.kernel_size == (3, 3) and isinstance(sl[1], nn.BatchNorm2d)
+            ok = ok and all(hasattr(b, "_conv1") and hasattr(b, "_bn2") and b._conv1.out_channels == 64 for b in blocks)
+            ph, vh = model._policy_head, model._value_head
+            ok = ok and ph[0].out_channels == 1 and vh[0].out_channels == 2 and isinstance(ph[4], nn.Linear) \
+                and isinstance(vh[4], nn.Linear) and isinstance(vh[6], nn.Linear)
+            n2 = ph[4].in_features
+            return bool(ok and n2 in (81, 225))
+        except Exception:
+            return False
+
+    def __init__(self, model: nn.Module):
+        if not self.supports(model):
+            raise EngineError("FusedTowerEvaluator: not a GomokuModel-family network (64-ch 3x3 residual tower)")
+        self.lib = load_library()
+        self.model = model
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise EngineError("FusedTowerEvaluator needs the model on a GPU")
+        self.n2 = model._policy_head[4].in_features
+        self.board = 15 if self.n2 == 225 else 9
+        self._buf = {}
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self) -> None:
+        m, dev = self.model, self.device
+        sl = list(m._shared_layers)
+        blocks = sl[3:]
+        w, b = _fold(sl[0], sl[1])
+        self.w0 = _pack3x3(w, 16).to(dev)
+        biases, wl = [b], []
+        for blk in blocks:
+            for conv, bn in ((blk._conv1, blk._bn1), (blk._conv2, blk._bn2)):
+                w, b = _fold(conv, bn)
+                wl.append(_pack3x3(w, 64))
+                biases.append(b)
+        self.n_layers = len(wl)
+        self.wl = (torch.stack(wl) if wl else torch.zeros(1, dtype=torch.bfloat16)).to(dev).contiguous()
+        self.bias = torch.stack(biases).to(dev).contiguous()
+        pw, pb = _fold(m._policy_head[0], m._policy_head[1])
+        vw, vb = _fold(m._value_head[0], m._value_head[1])
+        self.headw = torch.cat([pw.view(1, 64), vw.view(2, 64)]).to(dev).contiguous()
+        self.headb = torch.cat([pb.view(1), vb.view(2)]).to(dev).contiguous()
+        f = lambda t: t.detach().float().to(dev).contiguous()
+        pl, v1, v2 = m._policy_head[4], m._value_head[4], m._value_head[6]
+        self.pl_wt, self.pl_b = f(pl.weight).t().contiguous(), f(pl.bias)
+        self.v1_wt, self.v1_b = f(v1.weight).t().contiguous(), f(v1.bias)
+        self.v2_wt, self.v2_b = f(v2.weight).t().contiguous(), f(v2.bias)
+
+    def __call__(self, x: torch.Tensor, logits_out: torch.Tensor | None = None):
+        if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
+            raise EngineError("FusedTowerEvaluator expects a contiguous (B,9,N,N) bf16 batch on the model's GPU")
+        B = x.shape[0]
+        if B not in self._buf:
+            self._buf[B] = (torch.empty(B, self.n2, device=self.device), torch.empty(B, 2 * self.n2, device=self.device))
+        pfeat, vfeat = self._buf[B]
+        P = lambda t: C.c_void_p(t.data_ptr())
+        rc = self.lib.az_tower_forward(self.board, B, self.n_layers, P(x), P(self.w0), P(self.wl), P(self.bias),
+                                       P(self.headw), P(self.headb), P(pfeat), P(vfeat),
+                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise EngineError(f"az_tower_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
+        logits = torch.addmm(self.pl_b, pfeat, self.pl_wt, out=logits_out) if logits_out is not None \
+            else torch.addmm(self.pl_b, pfeat, self.pl_wt)
+        hid = torch.relu_(torch.addmm(self.v1_b, vfeat, self.v1_wt))
+        value = torch.tanh_(torch.addmm(self.v2_b, hid, self.v2_wt))
+        return logits, value

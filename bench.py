@@ -118,7 +118,9 @@ def main():
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--sims", type=int, default=0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--evaluator", default="model", choices=["model", "hash"])
+    ap.add_argument("--evaluator", default="auto", choices=["auto", "fused", "model", "hash"],
+                    help="fused = hand-written MFMA conv tower (az_tower.hip); model = the module's own PyTorch forward; "
+                         "auto = fused when the network is a GomokuModel-family tower and dtype is bf16")
     ap.add_argument("--preroll", type=int, default=96, help="cheap 2-sim move rounds that stagger game ages")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,7 +159,11 @@ def main():
 
     eng = Engine(game, slots, sims, board_size=n, nn_dtype=tdtype, device=dev)
     d = eng.dims
-    run = SelfPlayRunner(eng, model, sims, channels_last=True)
+    if args.evaluator == "auto":
+        from alphazero_amd.fused import FusedTowerEvaluator
+
+        args.evaluator = "fused" if (tdtype == torch.bfloat16 and FusedTowerEvaluator.supports(model)) else "model"
+    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(args.evaluator == "fused"))
     if args.evaluator == "hash":  # tree kernels alone (no network)
         run.evaluate = lambda: eng.eval_hash(run.nn_input, run.logits, run.values, 6.0)
     ring = HostSampleRing(max(4 * slots, 65536), (d.nn_channels, d.height, d.width), d.n_action)
@@ -284,11 +290,13 @@ def main():
                              "evals_per_sim": st["evals"] / max(st["sims"], 1)},
             "cpu_baseline": cpu,
         }
-        if args.evaluator == "model" and hasattr(model, "flops_per_eval"):
+        if args.evaluator in ("model", "fused") and hasattr(model, "flops_per_eval"):
             fl = model.flops_per_eval() * slots
             out["nn_eval"] = {"bound": "mfma", "ms_per_batch": nn_ms, "achieved": fl / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
                               "peak": 2500.0, "unit": "TFLOP/s", "frac": (fl / (nn_ms * 1e-3) / 1e12 / 2500.0) if nn_ms else 0.0,
-                              "flops_per_eval": model.flops_per_eval(), "share_of_step": nn_ms / max(nn_ms + sel_ms + exp_ms, 1e-9)}
+                              "flops_per_eval": model.flops_per_eval(), "share_of_step": nn_ms / max(nn_ms + sel_ms + exp_ms, 1e-9),
+                              "implementation": "az_tower.hip fused bf16 MFMA tower + torch head linears" if args.evaluator == "fused"
+                              else "PyTorch/MIOpen module forward"}
         if cpu:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
         print(json.dumps(out))

@@ -156,6 +156,20 @@ int az_reset_stats(az_engine *e, void *stream);
 int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *logits_dev,
                  float *values_dev, void *stream);
 
+/* No counterpart in the reference beyond the model contract (nn_models/base.py:17-19): a fused bf16 MFMA
+ * evaluator for the residual conv tower of the GomokuModel family (examples/gomoku/model.py:41-90):
+ * stem conv3x3(9->64), n_conv_layers/2 residual blocks of two conv3x3(64->64), the 1x1 head convs, all
+ * with eval-mode BatchNorm folded in by the host and ReLU fused, activations resident in LDS.
+ *   x_bf16_dev (n_boards, 9, N, N) bf16 = the batch az_select_gather writes with AZ_NN_BF16;
+ *   w0_dev [9][1][2][64][8] bf16, wl_dev [n_conv_layers][9][4][2][64][8] bf16 ([tap][k-step][k-half][co][8 ci]);
+ *   bias_dev [1+n_conv_layers][64] f32; headw_dev [3][64] f32, headb_dev [3] f32 (policy, value0, value1);
+ *   pfeat_dev (n_boards, N*N) f32 and vfeat_dev (n_boards, 2, N*N) f32 out: the inputs of the heads'
+ *   Linear layers (which stay in PyTorch).  board_size N in {9, 15}. */
+int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
+                     const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
+                     const float *headb_dev, float *pfeat_dev, float *vfeat_dev, void *stream);
+const char *az_tower_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

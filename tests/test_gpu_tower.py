@@ -1,0 +1,56 @@
+"""GPU test of the fused conv-tower evaluator (csrc/az_tower.hip) against the plain PyTorch fp32 forward of
+the same network.  Floating point: bf16 operands, f32 accumulation, bf16 activations between layers, so
+the bar is a bf16-level tolerance, stated below; the reference's model contract (nn_models/base.py:17-19)
+fixes shapes and ranges only."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomised(net):
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+    return net
+
+
+@pytest.mark.parametrize("board,blocks,batch", [(15, 2, 64), (15, 2, 1000), (15, 3, 33), (9, 2, 100), (9, 1, 7), (15, 0, 5)])
+def test_fused_tower_matches_fp32_forward(board, blocks, batch):
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(0)
+    net = _randomised(GomokuNet(board, 64, blocks)).eval().cuda()
+    assert FusedTowerEvaluator.supports(net)
+    ev = FusedTowerEvaluator(net)
+    x = torch.randint(-1, 2, (batch, 9, board, board), device="cuda").float()
+    x[:, 8] = torch.where(torch.rand(batch, 1, 1, device="cuda") < 0.5, -1.0, 1.0)  # player plane
+    with torch.inference_mode():
+        ref_p, ref_v = net(x)
+    p, v = ev(x.bfloat16().contiguous())
+    assert p.shape == ref_p.shape and v.shape == ref_v.shape and p.dtype == torch.float32
+    scale = float(ref_p.abs().max())
+    # bf16 has 8 significant bits; 2 + 2*blocks layers of rounding -> a few 1e-2 of the logit scale at worst
+    assert float((p - ref_p).abs().max()) <= 0.03 * scale + 0.02, float((p - ref_p).abs().max())
+    assert float((v - ref_v).abs().max()) <= 0.03
+    assert float((p - ref_p).abs().mean()) <= 0.004 * scale + 0.002
+    # and it must beat / match the plain bf16 PyTorch forward's own error
+    netb = GomokuNet(board, 64, blocks)
+    netb.load_state_dict(net.state_dict())
+    netb = netb.eval().cuda().bfloat16()
+    with torch.inference_mode():
+        bp, _ = netb(x.bfloat16())
+    assert float((p - ref_p).abs().mean()) <= 1.5 * float((bp.float() - ref_p).abs().mean()) + 1e-4
+
+
+def test_fused_tower_rejects_other_nets():
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet, TicTacToeNet
+
+    assert not FusedTowerEvaluator.supports(TicTacToeNet())
+    assert not FusedTowerEvaluator.supports(GomokuNet(15, 128, 2))
