@@ -14,7 +14,8 @@ So one step = slots x 400 simulations per GPU.  Inputs live in HBM; only finishe
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant hand-written tree kernel (k_select_gather): algorithmic bytes per launch
                   / mean launch time measured with HIP events on the launch stream, vs 8 TB/s HBM.
-  nn_eval      -- the network forward (PyTorch/MIOpen, MFMA): achieved TFLOP/s vs 2.5 PFLOP/s dense bf16.
+  nn_eval      -- the network forward (fused MFMA tower az_tower.hip, or PyTorch/MIOpen with --evaluator model):
+                  achieved TFLOP/s vs 2.5 PFLOP/s dense bf16.
   cpu_baseline -- the CPU oracle (oracle/, "port" of the reference path, proven equal to it on the
                   golden fixtures) timed on this box's host cores with the same network on torch-CPU.
 """
@@ -226,7 +227,8 @@ def main():
         return run.done
 
     def step(timed: bool):
-        publisher.publish()  # learner -> self-play weight push (RCCL broadcast; no-op at N = 1)
+        if publisher.publish() and run.fused is not None:  # learner -> self-play weight push (RCCL broadcast; no-op at N = 1)
+            run.fused.refresh()  # re-fold BatchNorm / re-pack the published weights for the fused tower
         done = timed_round() if timed else run.move_round(inv_tao)[1]
         collect(done)
 
