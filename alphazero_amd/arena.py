@@ -89,7 +89,7 @@ class SelfPlayRunner:
     def evaluate(self) -> None:
         if self.fused is not None:
             _, v = self.fused(self.nn_input, logits_out=self.logits)
-            self.values.copy_(v.view(-1), non_blocking=True)
+            self.values = v.view(-1)  # handed to expand_backup as is (no copy)
             return
         x = self.nn_input
         if x.device != self.model_device or x.dtype != self.model_dtype:

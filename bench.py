@@ -260,9 +260,17 @@ def main():
         elapsed = float(tmax[0])
     total_sims, total_games, total_plies = float(tt[1]), float(tt[2]), float(tt[3])
 
+    # what an empty event pair reads on this stream (record -> record): subtracted from every bracketed launch
+    empty = []
+    for _ in range(200):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b.record(); empty.append((a, b))
+    torch.cuda.synchronize()
+    ev_overhead = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
+
     if rank == 0:
         def mean_ms(pairs):
-            return sum(a.elapsed_time(b) for a, b in pairs) / max(len(pairs), 1)
+            return max(sum(a.elapsed_time(b) for a, b in pairs) / max(len(pairs), 1) - ev_overhead, 1e-6)
 
         nin = d.nn_channels * d.height * d.width
         launches = max(len(ev_sel), 1)
@@ -287,6 +295,7 @@ def main():
                          "frac": achieved / 8000.0, "traffic": None, "bytes_per_launch": dom[1], "ms_per_launch": dom[2]},
             "tree_kernels": {"k_select_gather": {"ms": sel_ms, "bytes": sel_bytes, "GBps": sel_bytes / max(sel_ms, 1e-9) / 1e6},
                              "k_expand_backup": {"ms": exp_ms, "bytes": exp_bytes, "GBps": exp_bytes / max(exp_ms, 1e-9) / 1e6},
+                             "event_pair_overhead_ms": ev_overhead,
                              "mean_depth": st["sum_depth"] / max(st["sims"], 1),
                              "mean_children_per_level": st["sum_children"] / max(st["sum_depth"], 1),
                              "evals_per_sim": st["evals"] / max(st["sims"], 1)},
