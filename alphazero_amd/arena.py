@@ -58,7 +58,7 @@ class SelfPlayRunner:
 
     def __init__(self, engine: Engine, model: torch.nn.Module, num_sims: int, alpha: float = ALPHA,
                  use_dirichlet: bool = True, reference_rng: bool = False, channels_last: bool = False,
-                 fused: bool = False):
+                 fused: bool = False, use_graph: bool = False):
         if num_sims > engine.max_sims:
             raise EngineError("num_sims exceeds the engine's max_sims")
         self.e, self.model, self.num_sims = engine, model, num_sims
@@ -77,6 +77,7 @@ class SelfPlayRunner:
         p = next(model.parameters(), None)
         self.model_device = p.device if p is not None else torch.device("cpu")
         self.model_dtype = p.dtype if p is not None else torch.float32
+        self.use_graph, self._graph = use_graph, None
         self.fused = None
         if fused:  # hand-written MFMA conv tower (csrc/az_tower.hip) instead of the module's own forward
             from .fused import FusedTowerEvaluator
@@ -120,15 +121,40 @@ class SelfPlayRunner:
             self.expo.exponential_(1)
         return self.expo
 
+    def sim_step(self, noise) -> None:
+        """one simulation in every active tree: select+gather -> network -> expand+backup"""
+        self.e.select_gather(self.nn_input)
+        self.evaluate()
+        self.e.expand_backup(self.logits, self.values, noise)
+
+    def _capture(self, noise) -> None:
+        """Capture one simulation step into a HIP graph (all buffers are persistent, the launches are
+        plain kernel launches on the capture stream): the inner loop is launch-bound for the small games."""
+        s = torch.cuda.Stream(self.e.device)
+        s.wait_stream(torch.cuda.current_stream(self.e.device))
+        with torch.cuda.stream(s):
+            for _ in range(2):  # warm up allocator / library handles outside capture (results are discarded by
+                self.sim_step(noise)  # the begin_search that follows)
+        torch.cuda.current_stream(self.e.device).wait_stream(s)
+        torch.cuda.synchronize(self.e.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.sim_step(noise)
+        self._graph, self._graph_noise = g, noise is not None
+
     def search(self) -> None:
         """num_sims simulations in every active tree (MCTS.search, core/MCTS_alphazero.py:128-178)"""
         noise = self.draw_noise()
         e = self.e
+        if self.use_graph and (self._graph is None or self._graph_noise != (noise is not None)):
+            self._capture(noise)
         e.begin_search()
+        if self._graph is not None and self.use_graph:
+            for _ in range(self.num_sims):
+                self._graph.replay()
+            return
         for _ in range(self.num_sims):
-            e.select_gather(self.nn_input)
-            self.evaluate()
-            e.expand_backup(self.logits, self.values, noise)
+            self.sim_step(noise)
 
     def move_round(self, inv_tao: torch.Tensor, forced: Optional[torch.Tensor] = None):
         """search + temperature sampling + step, for every active slot (training/self_play.py:36-83)"""

@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--evaluator", default="auto", choices=["auto", "fused", "model", "hash"],
                     help="fused = hand-written MFMA conv tower (az_tower.hip); model = the module's own PyTorch forward; "
                          "auto = fused when the network is a GomokuModel-family tower and dtype is bf16")
+    ap.add_argument("--graph", type=int, default=0, help="1: the timed steps replay the simulation step as a captured HIP graph "
+                    "(what the small, launch-bound games want); the per-kernel HIP-event times then come from one eager probe "
+                    "step run after the timed region.  0 (default): eager launches, events inside the timed region")
     ap.add_argument("--preroll", type=int, default=96, help="cheap 2-sim move rounds that stagger game ages")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,7 +167,7 @@ def main():
         from alphazero_amd.fused import FusedTowerEvaluator
 
         args.evaluator = "fused" if (tdtype == torch.bfloat16 and FusedTowerEvaluator.supports(model)) else "model"
-    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(args.evaluator == "fused"))
+    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(args.evaluator == "fused"), use_graph=bool(args.graph))
     if args.evaluator == "hash":  # tree kernels alone (no network)
         run.evaluate = lambda: eng.eval_hash(run.nn_input, run.logits, run.values, 6.0)
     ring = HostSampleRing(max(4 * slots, 65536), (d.nn_channels, d.height, d.width), d.n_action)
@@ -229,7 +232,7 @@ def main():
     def step(timed: bool):
         if publisher.publish() and run.fused is not None:  # learner -> self-play weight push (RCCL broadcast; no-op at N = 1)
             run.fused.refresh()  # re-fold BatchNorm / re-pack the published weights for the fused tower
-        done = timed_round() if timed else run.move_round(inv_tao)[1]
+        done = timed_round() if (timed and not args.graph) else run.move_round(inv_tao)[1]
         collect(done)
 
     for _ in range(args.warmup):
@@ -251,6 +254,15 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.check()
     st = eng.read_stats()
+    if args.graph:  # kernel times: one eager, event-bracketed probe step outside the timed region
+        eng.reset_stats()
+        keep = (finished_games, finished_plies)
+        collect(timed_round())
+        torch.cuda.synchronize()
+        finished_games, finished_plies = keep
+        st_probe = eng.read_stats()
+    else:
+        st_probe = st
 
     tt = torch.tensor([elapsed, float(st["sims"]), float(finished_games), float(finished_plies)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -275,6 +287,7 @@ def main():
         nin = d.nn_channels * d.height * d.width
         launches = max(len(ev_sel), 1)
         sel_ms, exp_ms, nn_ms = mean_ms(ev_sel), mean_ms(ev_exp), mean_ms(ev_nn)
+        st_all, st = st, st_probe  # byte counts must come from the same launches the events bracket
         # algorithmic bytes (DESIGN.md "bytes per simulation"): child record = P f32 + N i32 + Q f64 + act u16
         sel_bytes = (18.0 * st["sum_children"] + 22.0 * st["sum_depth"] + st["evals"] * (nin * esize + 4.0 * d.state_words)
                      + st["sims"] * (16.0 + 36.0 * d.state_words)) / launches
@@ -296,6 +309,8 @@ def main():
             "tree_kernels": {"k_select_gather": {"ms": sel_ms, "bytes": sel_bytes, "GBps": sel_bytes / max(sel_ms, 1e-9) / 1e6},
                              "k_expand_backup": {"ms": exp_ms, "bytes": exp_bytes, "GBps": exp_bytes / max(exp_ms, 1e-9) / 1e6},
                              "event_pair_overhead_ms": ev_overhead,
+                             "timed_with": "probe step after the timed region (timed steps replay a HIP graph)" if args.graph
+                             else "HIP events inside the timed region",
                              "mean_depth": st["sum_depth"] / max(st["sims"], 1),
                              "mean_children_per_level": st["sum_children"] / max(st["sum_depth"], 1),
                              "evals_per_sim": st["evals"] / max(st["sims"], 1)},
