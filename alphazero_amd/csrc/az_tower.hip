@@ -9,9 +9,11 @@
 // in PyTorch (hipBLASLt).  C ABI at the bottom; declared in include/az_engine.h.
 //
 // Mapping (one workgroup = 4 waves = BPW boards):
-//   LDS act[pos][64 ch] bf16, pos on a zero-padded (N+2)^2 grid, 128 B per position, the eight 16-byte
-//   channel chunks of a position XOR-swizzled with (pos>>1)&7 so that the 16 lanes of a ds_read_b128
-//   group hit 16 different bank quads.
+//   LDS act[cell][64 ch] bf16, cells packed without halo (cell = board*N*N + row*N + col), 128 B per
+//   cell, the eight 16-byte channel chunks of a cell XOR-swizzled with (cell>>1)&7: the 32 lanes of a
+//   position tile hold 32 CONSECUTIVE cells, a tap shifts all of them by the same amount, so the 16
+//   lanes of every ds_read_b128 group hit 16 different bank quads (conflict-free).  Taps that fall off
+//   the board read a 16-byte zero slot instead (per-lane 9-bit tap-validity mask).
 //   GEMM orientation: D[co][pos] = sum_k W[co][k] * X[k][pos], k = (tap, ci).  A = weights (rows = out
 //   channels), B = activations (cols = positions): the accumulator then holds, per lane, ONE position
 //   and 4-channel runs, which pack into 8-byte LDS stores in the epilogue.
@@ -45,47 +47,82 @@ __device__ __forceinline__ int act_addr(int p, int chunk) { return p * 128 + ((c
 
 template <int N, int BPW>
 struct Geo {
-  static constexpr int P = N + 2, NPOS = P * P, NV = N * N, NVT = BPW * NV;
-  static constexpr int ACT_BYTES = BPW * NPOS * 128;
+  static constexpr int NV = N * N, NVT = BPW * NV;
+  static constexpr int ZERO_OFF = NVT * 128;       // 16 zero bytes (padded to 256)
+  static constexpr int ACT_BYTES = NVT * 128 + 256;
   static_assert(NVT <= 256, "8 position tiles of 32");
 };
 
+// async global -> LDS copy of 16 B per lane: the LDS destination is the wave-uniform `lds_base` + lane*16
+__device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
+                                   (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)lds_base, 16, 0, 0);
+}
+
+#ifndef AZ_TOWER_STAGE_TAPS
+#define AZ_TOWER_STAGE_TAPS 3  // taps staged per barrier: 3 = one kernel row (48 KiB of LDS), 1 = one tap (16 KiB)
+#endif
+#ifndef AZ_TOWER_WAVES_PER_SIMD
+#define AZ_TOWER_WAVES_PER_SIMD 2
+#endif
+constexpr int ST = AZ_TOWER_STAGE_TAPS;
+constexpr int STAGE_BYTES = ST * TAP_BYTES;
+
+// stage ST taps of weights (ST*KS*2 KiB, [tap][ks][half][co][8] bf16) into an LDS buffer:
+// 1 KiB per wave-instruction, chunks dealt round-robin to the 4 waves
+template <int KS>
+__device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave, int lane) {
+  constexpr int NCHUNK = ST * KS * 2;
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c += 4)
+    if (c + wave < NCHUNK) glds16(wg_src + (c + wave) * 1024 + lane * 16, dst + (c + wave) * 1024);
+}
+
 // one conv layer, in registers: acc[pt][ct] += W * X.  KS = 16-channel k-steps per tap (1 or 4).
-template <int KS, int P>
+// pp[pt] = this lane's cell, vm[pt] = bit t set when tap t of that cell is on the board.
+// Weights are staged ST taps at a time, double buffered: 9/ST barriers per layer.
+template <int KS, int N, int ZERO_OFF>
 __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, const char *wg, int tid, int lane,
-                                           const int (&pp)[2], f32x16 (&acc)[2][2]) {
-  constexpr int TB = KS * 2048;  // bytes per tap: 2 KiB (stem, threads 0..127 move it) or 8 KiB (2 x 16 B per thread)
-  const int h = lane >> 5, r = lane & 31;
-  const bool mover = (KS == 4) || tid < 128;
-  const int o0 = tid * 16, o1 = 4096 + tid * 16;
-  // tap 0 -> buffer 0
-  if (mover) *(uint4 *)(wbuf + o0) = *(const uint4 *)(wg + o0);
-  if (KS == 4) *(uint4 *)(wbuf + o1) = *(const uint4 *)(wg + o1);
+                                           const int (&pp)[2], const uint32_t (&vm)[2], f32x16 (&acc)[2][2]) {
+  constexpr int TB = KS * 2048;  // bytes per tap
+  constexpr int NSTAGE = 9 / ST;
+  const int h = lane >> 5, r = lane & 31, wave = tid >> 6;
+  stage_w<KS>(wg, wbuf, wave, lane);  // stage 0 -> buffer 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll 1
-  for (int tap = 0; tap < 9; ++tap) {
-    uint4 s0 = make_uint4(0, 0, 0, 0), s1 = make_uint4(0, 0, 0, 0);
-    const char *wgn = wg + (tap < 8 ? tap + 1 : 8) * TB;  // tap 8 re-reads its own slice (discarded)
-    if (mover) s0 = *(const uint4 *)(wgn + o0);
-    if (KS == 4) s1 = *(const uint4 *)(wgn + o1);
-    const char *wc = wbuf + (tap & 1) * TAP_BYTES;
-    const int d = (tap / 3 - 1) * P + (tap % 3 - 1);
+  for (int sg = 0; sg < NSTAGE; ++sg) {
+    // the DMA of the next stage's weights runs under this stage's MFMAs
+    if (sg < NSTAGE - 1) stage_w<KS>(wg + (sg + 1) * ST * TB, wbuf + ((sg + 1) & 1) * STAGE_BYTES, wave, lane);
+    const char *wst = wbuf + (sg & 1) * STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int chunk = ks * 2 + h;
-      const bf16x8 a0 = *(const bf16x8 *)(wc + chunk * 1024 + r * 16);
-      const bf16x8 a1 = *(const bf16x8 *)(wc + chunk * 1024 + 512 + r * 16);
+    for (int j = 0; j < ST; ++j) {
+      const int tap = sg * ST + j;
+      const char *wc = wst + j * TB;
+      const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
+      int q[2], sw[2];
+      bool on[2];
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
-        const bf16x8 b = *(const bf16x8 *)(act + act_addr(pp[pt] + d, chunk));
-        acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[pt][0], 0, 0, 0);
-        acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[pt][1], 0, 0, 0);
+        q[pt] = (pp[pt] + d) * 128;
+        sw[pt] = ((pp[pt] + d) >> 1) & 7;
+        on[pt] = (vm[pt] >> tap) & 1u;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int chunk = ks * 2 + h;
+        const bf16x8 a0 = *(const bf16x8 *)(wc + chunk * 1024 + r * 16);
+        const bf16x8 a1 = *(const bf16x8 *)(wc + chunk * 1024 + 512 + r * 16);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const bf16x8 b = *(const bf16x8 *)(act + (on[pt] ? q[pt] + ((chunk ^ sw[pt]) << 4) : ZERO_OFF));
+          acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[pt][0], 0, 0, 0);
+          acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[pt][1], 0, 0, 0);
+        }
       }
     }
-    char *wn = wbuf + ((tap + 1) & 1) * TAP_BYTES;  // after tap 8 this refills buffer 1, which nobody reads again
-    if (mover) *(uint4 *)(wn + o0) = s0;
-    if (KS == 4) *(uint4 *)(wn + o1) = s1;
-    __syncthreads();  // after tap 8: every wave has finished reading act -> the epilogue may overwrite it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next stage has landed
+    __syncthreads();  // after the last stage: every wave has finished reading act -> the epilogue may overwrite it
   }
 }
 
@@ -127,7 +164,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 // wl: [L][9][4][2][64][8] bf16.  bias: [1+L][64] f32.  headw: [3][64] f32 (policy, value0, value1),
 // headb: [3].  pfeat: (G, NV) f32, vfeat: (G, 2, NV) f32 (= the inputs of the heads' Linear layers).
 template <int N, int BPW>
-__global__ __launch_bounds__(256, 2) void k_tower(const uint16_t *__restrict__ x, int G, const char *__restrict__ w0,
+__global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const uint16_t *__restrict__ x, int G, const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
                                                float *__restrict__ pfeat, float *__restrict__ vfeat) {
@@ -135,21 +172,29 @@ __global__ __launch_bounds__(256, 2) void k_tower(const uint16_t *__restrict__ x
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *act = smem;
   char *wbuf = smem + Q::ACT_BYTES;
-  float *hw = (float *)(wbuf + 2 * TAP_BYTES);  // 3*64 + 3 floats
+  float *hw = (float *)(wbuf + 2 * STAGE_BYTES);  // 3*64 + 3 floats
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  for (int i = tid; i < Q::ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // halos stay zero
+  for (int i = tid; i < Q::ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero slot
   for (int i = tid; i < 3 * CH + 3; i += 256) hw[i] = i < 3 * CH ? headw[i] : headb[i - 3 * CH];
 
-  // this lane's two positions (B-operand column / accumulator column): tile = 2*wave + pt
+  // this lane's two cells (B-operand column / accumulator column): tile = 2*wave + pt
   int pp[2];
   bool ok[2];
+  uint32_t vm[2];
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt) {
     const int m = (2 * wave + pt) * 32 + (lane & 31);
     ok[pt] = m < Q::NVT;
-    const int mm = ok[pt] ? m : 0, b = mm / Q::NV, cell = mm % Q::NV;
-    pp[pt] = b * Q::NPOS + (cell / N + 1) * Q::P + (cell % N + 1);
+    pp[pt] = ok[pt] ? m : 0;
+    const int cell = pp[pt] % Q::NV, row = cell / N, col = cell % N;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int rr = row + t / 3 - 1, cc = col + t % 3 - 1;
+      if (rr >= 0 && rr < N && cc >= 0 && cc < N) mask |= 1u << t;
+    }
+    vm[pt] = ok[pt] ? mask : 0u;
   }
   __syncthreads();
 
@@ -164,9 +209,8 @@ __global__ __launch_bounds__(256, 2) void k_tower(const uint16_t *__restrict__ x
 #pragma unroll
         for (int ch = 0; ch < 9; ++ch) c[ch >> 1] |= (uint32_t)xr[ch * Q::NV] << ((ch & 1) * 16);
       }
-      const int p = b * Q::NPOS + (cell / N + 1) * Q::P + (cell % N + 1);
-      *(uint4 *)(act + act_addr(p, 0)) = make_uint4(c[0], c[1], c[2], c[3]);
-      *(uint4 *)(act + act_addr(p, 1)) = make_uint4(c[4], c[5], c[6], c[7]);
+      *(uint4 *)(act + act_addr(m, 0)) = make_uint4(c[0], c[1], c[2], c[3]);
+      *(uint4 *)(act + act_addr(m, 1)) = make_uint4(c[4], c[5], c[6], c[7]);
     }
     __syncthreads();
 
@@ -174,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(const uint16_t *__restrict__ x
     uint2 res[2][2][4];
     // ---- stem
     zero_acc(acc);
-    conv_layer<1, Q::P>(act, wbuf, w0, tid, lane, pp, acc);
+    conv_layer<1, N, Q::ZERO_OFF>(act, wbuf, w0, tid, lane, pp, vm, acc);
     epilogue<false>(act, bias, lane, pp, ok, acc, res);
     __syncthreads();
     // ---- residual blocks
@@ -187,11 +231,11 @@ __global__ __launch_bounds__(256, 2) void k_tower(const uint16_t *__restrict__ x
 #pragma unroll
           for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pp[pt], ct * 4 + q) + 8 * h);
       zero_acc(acc);
-      conv_layer<4, Q::P>(act, wbuf, wl + (size_t)l * 9 * TAP_BYTES, tid, lane, pp, acc);
+      conv_layer<4, N, Q::ZERO_OFF>(act, wbuf, wl + (size_t)l * 9 * TAP_BYTES, tid, lane, pp, vm, acc);
       epilogue<false>(act, bias + (1 + l) * CH, lane, pp, ok, acc, res);
       __syncthreads();
       zero_acc(acc);
-      conv_layer<4, Q::P>(act, wbuf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid, lane, pp, acc);
+      conv_layer<4, N, Q::ZERO_OFF>(act, wbuf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid, lane, pp, vm, acc);
       epilogue<true>(act, bias + (2 + l) * CH, lane, pp, ok, acc, res);
       __syncthreads();
     }
@@ -199,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void k_tower(const uint16_t *__restrict__ x
     for (int m = tid; m < Q::NVT; m += 256) {
       const int b = m / Q::NV, cell = m % Q::NV, g = grp * BPW + b;
       if (g >= G) continue;
-      const int p = b * Q::NPOS + (cell / N + 1) * Q::P + (cell % N + 1);
+      const int p = m;
       float s0 = hw[3 * CH + 0], s1 = hw[3 * CH + 1], s2 = hw[3 * CH + 2];
 #pragma unroll
       for (int chunk = 0; chunk < 8; ++chunk) {
@@ -241,18 +285,18 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
   hipError_t err;
   if (board_size == 15) {
     constexpr int BPW = 1;
-    const size_t lds = Geo<15, BPW>::ACT_BYTES + 2 * TAP_BYTES + 1024;
+    const size_t lds = Geo<15, BPW>::ACT_BYTES + 2 * STAGE_BYTES + 1024;
     static bool attr15 = false;
     if (!attr15) { (void)hipFuncSetAttribute((const void *)k_tower<15, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr15 = true; }
-    const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 512 ? groups : 512;
+    const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 256 * AZ_TOWER_WAVES_PER_SIMD ? groups : 256 * AZ_TOWER_WAVES_PER_SIMD;
     hipLaunchKernelGGL((k_tower<15, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, n_boards, (const char *)w0_dev,
                        (const char *)wl_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
   } else if (board_size == 9) {
     constexpr int BPW = 3;
-    const size_t lds = Geo<9, BPW>::ACT_BYTES + 2 * TAP_BYTES + 1024;
+    const size_t lds = Geo<9, BPW>::ACT_BYTES + 2 * STAGE_BYTES + 1024;
     static bool attr9 = false;
     if (!attr9) { (void)hipFuncSetAttribute((const void *)k_tower<9, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr9 = true; }
-    const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 512 ? groups : 512;
+    const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 256 * AZ_TOWER_WAVES_PER_SIMD ? groups : 256 * AZ_TOWER_WAVES_PER_SIMD;
     hipLaunchKernelGGL((k_tower<9, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, n_boards, (const char *)w0_dev,
                        (const char *)wl_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
   } else {
