@@ -495,6 +495,57 @@ __global__ __launch_bounds__(64) void k_emit_samples(View v, const int32_t *slot
   }
 }
 
+// ------------------------------------------------------------------------- augmentation -------
+// The 8-fold symmetry expansion the reference's pools apply on put:
+// utils/data_enhancer.py:13-70 for the stone games (for k in 0..3: rot90(k), then rot90(k) + flip of the
+// last dim) and examples/dots_and_boxes/game.py:158-320 for dots-and-boxes (edge / box permutations, where
+// "flip" is a transpose).  Gather form: output variant t = 2k + flip of sample i goes to row
+// (write_idx + 8 i + t) mod capacity, i.e. straight into ring-buffer layout (utils/share_ring_buffer.py:39-46).
+struct AugTables {
+  uint8_t invEdge[8][24];  // dots-and-boxes: source action of destination action, per variant
+  uint8_t invBox[8][9];
+};
+
+template <class GT>
+__global__ __launch_bounds__(64) void k_augment(AugTables tb, const float *in_s, const float *in_p, const float *in_z,
+                                                float *out_s, float *out_p, float *out_z, long long cap, long long wr) {
+  const int i = blockIdx.x, t = blockIdx.y, lane = threadIdx.x, k = t >> 1;
+  const bool flip = t & 1;
+  constexpr int A = GT::A, HW = GT::HW, NIN = GT::CIN * GT::HW, N = GT::H;
+  long long row = wr + 8ll * i + t;
+  if (cap > 0) row %= cap;
+  const float *is = in_s + (size_t)i * NIN, *ip = in_p + (size_t)i * A;
+  float *os = out_s + (size_t)row * NIN, *op = out_p + (size_t)row * A;
+  if (GT::CS == 1) {
+    auto src = [&](int cell) {
+      const int oi = cell / N, oj = cell % N, jj = flip ? N - 1 - oj : oj;
+      const int si = k == 0 ? oi : (k == 1 ? jj : (k == 2 ? N - 1 - oi : N - 1 - jj));
+      const int sj = k == 0 ? jj : (k == 1 ? N - 1 - oi : (k == 2 ? N - 1 - jj : oi));
+      return si * N + sj;
+    };
+    for (int idx = lane; idx < NIN; idx += 64) os[idx] = is[(idx / HW) * HW + src(idx % HW)];
+    for (int a = lane; a < A; a += 64) op[a] = ip[src(a)];
+  } else {
+    for (int idx = lane; idx < NIN; idx += 64) {
+      const int c = idx / HW, cell = idx % HW, r = cell >> 2, col = cell & 3;
+      float v = 0.0f;
+      if (c == GT::CIN - 1) v = is[idx];
+      else {
+        const int blk = c / 3, ch = c % 3;
+        if (ch == 2) {
+          if (r < 3 && col < 3) { const int b = tb.invBox[t][r * 3 + col]; v = is[(blk * 3 + 2) * HW + (b / 3) * 4 + b % 3]; }
+        } else if (ch == 0 ? col < 3 : r < 3) {
+          const int a = tb.invEdge[t][ch == 0 ? r * 3 + col : 12 + r * 4 + col];
+          v = a < 12 ? is[(blk * 3) * HW + (a / 3) * 4 + a % 3] : is[(blk * 3 + 1) * HW + ((a - 12) / 4) * 4 + (a - 12) % 4];
+        }
+      }
+      os[idx] = v;
+    }
+    for (int a = lane; a < A; a += 64) op[a] = ip[tb.invEdge[t][a]];
+  }
+  if (lane == 0) out_z[row] = in_z[i];
+}
+
 // ------------------------------------------------------------------------- small kernels ------
 template <class GT>
 __global__ void k_reset_games(View v, const uint8_t *mask) {
@@ -836,6 +887,46 @@ int az_emit_samples(az_engine *e, const int32_t *slots_dev, const int32_t *offse
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_emit_samples<GT>), dim3(n_games, e->dims.max_plies), dim3(64), 0, (hipStream_t)stream, e->v,
                                     slots_dev, offsets_dev, states_dev, pis_dev, z_dev));
   return launch_check(e, "k_emit_samples");
+}
+
+static void dab_rot(int &r, int &c, int k, int n) {  // examples/dots_and_boxes/game.py:305-313 on an n x n grid
+  for (int q = 0; q < (k & 3); ++q) { const int nr = n - 1 - c, nc = r; r = nr; c = nc; }
+}
+static AugTables make_aug_tables() {
+  AugTables tb;
+  for (int t = 0; t < 8; ++t) {
+    const int k = t >> 1;
+    const bool flip = t & 1;
+    for (int a = 0; a < 24; ++a) {  // _transform_edge :261-292
+      const bool hz = a < 12;
+      int r1 = hz ? a / 3 : (a - 12) / 4, c1 = hz ? a % 3 : (a - 12) % 4;
+      int r2 = hz ? r1 : r1 + 1, c2 = hz ? c1 + 1 : c1;
+      dab_rot(r1, c1, k, 4);
+      dab_rot(r2, c2, k, 4);
+      if (flip) { int x = r1; r1 = c1; c1 = x; x = r2; r2 = c2; c2 = x; }
+      const int na = (r1 == r2) ? r1 * 3 + (c1 < c2 ? c1 : c2) : 12 + (r1 < r2 ? r1 : r2) * 4 + c1;
+      tb.invEdge[t][na] = (uint8_t)a;
+    }
+    for (int b = 0; b < 9; ++b) {  // _transform_box :294-303
+      int r = b / 3, c = b % 3;
+      dab_rot(r, c, k, 3);
+      if (flip) { const int x = r; r = c; c = x; }
+      tb.invBox[t][r * 3 + c] = (uint8_t)b;
+    }
+  }
+  return tb;
+}
+
+int az_augment_samples(az_engine *e, int32_t n, const float *states_dev, const float *pis_dev, const float *z_dev,
+                       float *out_states_dev, float *out_pis_dev, float *out_z_dev, int64_t ring_capacity,
+                       int64_t ring_write_idx, void *stream) {
+  if (!e || !states_dev || !pis_dev || !z_dev || !out_states_dev || !out_pis_dev || !out_z_dev || n < 0) return AZ_EINVAL;
+  if (ring_capacity < 0 || ring_write_idx < 0 || (ring_capacity > 0 && ring_capacity < 8)) { e->err = "bad ring arguments"; return AZ_EINVAL; }
+  if (n == 0) return AZ_OK;
+  static const AugTables tb = make_aug_tables();
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_augment<GT>), dim3(n, 8), dim3(64), 0, (hipStream_t)stream, tb, states_dev, pis_dev, z_dev,
+                                    out_states_dev, out_pis_dev, out_z_dev, (long long)ring_capacity, (long long)ring_write_idx));
+  return launch_check(e, "k_augment");
 }
 
 int az_read_stats(az_engine *e, az_stats *out, void *stream) {

@@ -40,7 +40,7 @@ class AzStats(C.Structure):
 EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check", "az_reset_games",
            "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_root_policy",
            "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
-           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error"]
+           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_augment_samples"]
 
 _lib = None
 
@@ -76,6 +76,7 @@ def load_library() -> C.CDLL:
     lib.az_read_stats.argtypes = [vp, C.POINTER(AzStats), vp]
     lib.az_reset_stats.argtypes = [vp, vp]
     lib.az_eval_hash.argtypes = [vp, vp, C.c_float, vp, vp, vp]
+    lib.az_augment_samples.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
     lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
@@ -270,6 +271,25 @@ class Engine:
             self._ck(self.lib.az_emit_samples(self._h, _ptr(s_dev), _ptr(o_dev), n, _ptr(states), _ptr(pis), _ptr(z),
                                               self._stream()))
         return states, pis, z, offs
+
+    def augment_samples(self, states, pis, zs, out=None, ring_capacity: int = 0, ring_write_idx: int = 0):
+        """8-fold symmetry expansion on the device (the pools' get_enhanced_data); -> (states (8n,.), pis, z) or
+        writes rows (ring_write_idx + 8 i + t) % ring_capacity of the given out buffers."""
+        d = self.dims
+        n = int(states.shape[0])
+        states = states.reshape(n, d.nn_numel)
+        self._expect(states, (n, d.nn_numel), torch.float32, "states")
+        self._expect(pis, (n, d.n_action), torch.float32, "pis")
+        self._expect(zs, (n,), torch.float32, "zs")
+        if out is None:
+            out = (self.new(8 * n, d.nn_numel), self.new(8 * n, d.n_action), self.new(8 * n))
+        os_, op, oz = out
+        rows = ring_capacity or 8 * n
+        if os_.numel() < rows * d.nn_numel or op.numel() < rows * d.n_action or oz.numel() < rows:
+            raise EngineError("augment_samples: out buffers are smaller than the ring / 8n rows")
+        self._ck(self.lib.az_augment_samples(self._h, n, _ptr(states), _ptr(pis), _ptr(zs), _ptr(os_), _ptr(op), _ptr(oz),
+                                             ring_capacity, ring_write_idx, self._stream()))
+        return out
 
     def read_stats(self) -> dict:
         s = AzStats()

@@ -145,6 +145,16 @@ int az_game_info(az_engine *e, int32_t *plies_dev, int32_t *player_dev, uint8_t 
 int az_emit_samples(az_engine *e, const int32_t *slots_dev, const int32_t *offsets_dev, int32_t n_games,
                     float *states_dev, float *pis_dev, float *z_dev, void *stream);
 
+/* the 8-fold symmetry expansion the reference's pools apply on every put
+ * (utils/experience_pool.py:27-31 -> game_cls.get_enhanced_data: utils/data_enhancer.py:13-70;
+ * examples/dots_and_boxes/game.py:158-320), on the device: sample i (rows of states_dev (n, C_in*H*W),
+ * pis_dev (n, A), z_dev (n)) yields 8 samples, in the reference's order (rot90 k, then its flip, k = 0..3),
+ * written to rows (ring_write_idx + 8 i + t) mod ring_capacity of the out buffers, i.e. in the layout of
+ * utils/share_ring_buffer.py:39-46; ring_capacity 0 = no wrap (rows 8 i + t). */
+int az_augment_samples(az_engine *e, int32_t n, const float *states_dev, const float *pis_dev, const float *z_dev,
+                       float *out_states_dev, float *out_pis_dev, float *out_z_dev, int64_t ring_capacity,
+                       int64_t ring_write_idx, void *stream);
+
 /* Counters for the roofline (algorithmic bytes per simulation need the measured mean depth and mean
  * children per visited node).  Synchronises. */
 int az_read_stats(az_engine *e, az_stats *out, void *stream);

@@ -437,7 +437,58 @@ def make_selfplay():
     np.savez_compressed(os.path.join(OUT, "selfplay.npz"), **out)
 
 
+# --------------------------------------------------------------------------- augmentation KATs ----
+def make_augment():
+    """8-fold symmetry expansion applied by the pools on put (utils/experience_pool.py:27-31,
+    utils/share_ring_buffer.py put) = game_cls.get_enhanced_data: utils/data_enhancer.py:13-70 for the
+    stone games, examples/dots_and_boxes/game.py:158-320 for dots-and-boxes."""
+    rng = np.random.default_rng(99)
+    out = {}
+    GomokuGame.BOARD_SIZE = 15
+
+    def case(tag, game_cls, cin, h, w, A, n):
+        st = rng.integers(-1, 2, size=(n, cin, h, w)).astype(np.float32)
+        if game_cls is DotsAndBoxesGame:  # only legal cells are ever non-zero; edges are 0/1
+            st[:] = 0
+            for b in range(8):
+                st[:, 3 * b, :, :3] = rng.integers(0, 2, size=(n, 4, 3))
+                st[:, 3 * b + 1, :3, :] = rng.integers(0, 2, size=(n, 3, 4))
+                st[:, 3 * b + 2, :3, :3] = rng.integers(-1, 2, size=(n, 3, 3))
+        st[:, -1] = rng.choice([-1.0, 1.0], size=(n, 1, 1))
+        pi = rng.random((n, A)).astype(np.float32)
+        z = rng.choice([-1.0, 0.0, 1.0], size=n).astype(np.float32)
+        outs_s, outs_p, outs_z = [], [], []
+        for i in range(n):
+            res = game_cls.get_enhanced_data(torch.from_numpy(st[i:i + 1]), torch.from_numpy(pi[i:i + 1]),
+                                             torch.tensor([z[i]]))
+            assert len(res) == 8
+            for s_, p_, z_ in res:
+                outs_s.append(s_.reshape(-1).numpy().copy())
+                outs_p.append(p_.reshape(-1).numpy().copy())
+                outs_z.append(float(z_.reshape(-1)[0]))
+        out[f"{tag}__in_states"] = st.astype(np.int8)
+        out[f"{tag}__in_pis"] = pi
+        out[f"{tag}__in_z"] = z
+        out[f"{tag}__out_states"] = np.array(outs_s).astype(np.int8)
+        out[f"{tag}__out_pis"] = np.array(outs_p, np.float32)
+        out[f"{tag}__out_z"] = np.array(outs_z, np.float32)
+        print("augment", tag, n, "samples")
+
+    case("tictactoe", TicTacToeGame, 9, 3, 3, 9, 6)
+    case("dab", DotsAndBoxesGame, 25, 4, 4, 24, 6)
+    case("gomoku15", GomokuGame, 9, 15, 15, 225, 3)
+    case("gomoku9", GomokuGame, 9, 9, 9, 81, 4)
+    out["tags"] = np.array(["tictactoe", "dab", "gomoku15", "gomoku9"])
+    np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
+
+
 if __name__ == "__main__":
-    make_rules()
-    make_search()
-    make_selfplay()
+    which = sys.argv[1:] or ["rules", "search", "selfplay", "augment"]
+    if "rules" in which:
+        make_rules()
+    if "search" in which:
+        make_search()
+    if "selfplay" in which:
+        make_selfplay()
+    if "augment" in which:
+        make_augment()

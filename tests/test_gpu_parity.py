@@ -225,3 +225,35 @@ def test_full_size_invariants():
     assert bool((visits == visits[0:1]).all())
     st = eng.read_stats()
     assert st["sims"] == G * sims and st["evals"] == G * sims
+
+
+@pytest.mark.parametrize("tag", ["tictactoe", "dab", "gomoku15", "gomoku9"])
+def test_augmentation_matches_reference_golden(tag):
+    """az_augment_samples == the reference's get_enhanced_data (recorded), bit-exact, incl. ring wrap-around"""
+    import os
+
+    from .conftest import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "augment.npz"))
+    game, n = game_of(tag)
+    eng = _engine(game, n, 1, 2)
+    st = torch.from_numpy(z[f"{tag}__in_states"].astype(np.float32)).cuda()
+    pi = torch.from_numpy(z[f"{tag}__in_pis"]).cuda()
+    zz = torch.from_numpy(z[f"{tag}__in_z"]).cuda()
+    k = st.shape[0]
+    os_, op, oz = eng.augment_samples(st.reshape(k, -1).contiguous(), pi, zz)
+    assert np.array_equal(os_.cpu().numpy().astype(np.int8), z[f"{tag}__out_states"])
+    assert np.array_equal(op.cpu().numpy(), z[f"{tag}__out_pis"])
+    assert np.array_equal(oz.cpu().numpy(), z[f"{tag}__out_z"])
+    # ring layout: capacity 8k-3 rows, start 5 => the last rows wrap to the front
+    cap, wr = 8 * k - 3, 5
+    ring = (torch.zeros(cap, eng.dims.nn_numel, device="cuda"), torch.zeros(cap, eng.dims.n_action, device="cuda"),
+            torch.zeros(cap, device="cuda"))
+    eng.augment_samples(st.reshape(k, -1).contiguous(), pi, zz, out=ring, ring_capacity=cap, ring_write_idx=wr)
+    torch.cuda.synchronize()
+    want = z[f"{tag}__out_pis"]
+    got = ring[1].cpu().numpy()
+    for j in range(3, 8 * k):  # rows 0..2 were overwritten by the wrapped tail
+        assert np.array_equal(got[(wr + j) % cap], want[j])
+    for j in range(8 * k - 3, 8 * k):
+        assert np.array_equal(got[(wr + j) % cap], want[j])

@@ -116,3 +116,19 @@ def test_expf_logf_accuracy(oracle):
         assert abs(p[1] - want) <= 3e-7 * want + 1e-38
     for x, y in [(0.5, 2.0), (0.02, 10.0), (0.9, 1.0 / 0.7), (1.0, 3.0), (0.0, 2.0), (0.3, 1.0)]:
         assert abs(oracle.powf(x, y) - x ** y) <= 2e-5 * (x ** y) + 1e-30
+
+
+@pytest.mark.parametrize("tag", ["tictactoe", "dab", "gomoku15", "gomoku9"])
+def test_augmentation_kat(tag):
+    """oracle/augment.py (numpy) == the reference's get_enhanced_data on every golden sample, bit-exact"""
+    from oracle import augment as AUG
+
+    z = np.load(os.path.join(GOLDEN, "augment.npz"))
+    game, _ = game_of(tag)
+    st, pi, zz = z[f"{tag}__in_states"].astype(np.float32), z[f"{tag}__in_pis"], z[f"{tag}__in_z"]
+    for i in range(st.shape[0]):
+        outs, outp, outz = AUG.augment(game, st[i], pi[i], zz[i])
+        for t in range(8):
+            assert np.array_equal(outs[t].reshape(-1).astype(np.int8), z[f"{tag}__out_states"][8 * i + t]), (i, t)
+            assert np.array_equal(outp[t], z[f"{tag}__out_pis"][8 * i + t]), (i, t)
+            assert outz[t] == z[f"{tag}__out_z"][8 * i + t]
