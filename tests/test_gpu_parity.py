@@ -245,15 +245,14 @@ def test_augmentation_matches_reference_golden(tag):
     assert np.array_equal(os_.cpu().numpy().astype(np.int8), z[f"{tag}__out_states"])
     assert np.array_equal(op.cpu().numpy(), z[f"{tag}__out_pis"])
     assert np.array_equal(oz.cpu().numpy(), z[f"{tag}__out_z"])
-    # ring layout: capacity 8k-3 rows, start 5 => the last rows wrap to the front
-    cap, wr = 8 * k - 3, 5
+    # ring layout: 8k + 3 rows, writing starts at row 10 => the last 7 samples wrap to the front
+    cap, wr = 8 * k + 3, 10
     ring = (torch.zeros(cap, eng.dims.nn_numel, device="cuda"), torch.zeros(cap, eng.dims.n_action, device="cuda"),
             torch.zeros(cap, device="cuda"))
     eng.augment_samples(st.reshape(k, -1).contiguous(), pi, zz, out=ring, ring_capacity=cap, ring_write_idx=wr)
     torch.cuda.synchronize()
-    want = z[f"{tag}__out_pis"]
-    got = ring[1].cpu().numpy()
-    for j in range(3, 8 * k):  # rows 0..2 were overwritten by the wrapped tail
-        assert np.array_equal(got[(wr + j) % cap], want[j])
-    for j in range(8 * k - 3, 8 * k):
-        assert np.array_equal(got[(wr + j) % cap], want[j])
+    gs, gp, gz = (t.cpu().numpy() for t in ring)
+    for j in range(8 * k):
+        r = (wr + j) % cap
+        assert np.array_equal(gp[r], z[f"{tag}__out_pis"][j]) and gz[r] == z[f"{tag}__out_z"][j]
+        assert np.array_equal(gs[r].astype(np.int8), z[f"{tag}__out_states"][j])
