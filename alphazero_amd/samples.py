@@ -72,3 +72,66 @@ class WeightPublisher:
 def games_for_rank(n_games: int, rank: int, world: int) -> range:
     """Game ids owned by a rank: game g lives on rank g % world; no game ever moves."""
     return range(rank, n_games, world)
+
+
+class DeviceSampleRing:
+    """The reference's ring buffer (utils/share_ring_buffer.py:39-46,129-160) resident in HBM, for a learner on
+    the same GPU: states (cap,1,C,H,W), prior (cap,1,A), values (cap,1), overwrite-oldest,
+    ``sample`` draws with replacement from [0, size).  ``put_games`` runs the 8-fold augmentation on the device
+    (az_augment_samples) straight into ring layout, so no sample ever visits the host."""
+
+    def __init__(self, engine, capacity: int):
+        d = engine.dims
+        if capacity < 8:
+            raise ValueError("capacity must be >= 8")
+        self.e, self.capacity = engine, capacity
+        dev = engine.device
+        self._states = torch.zeros((capacity, 1, d.nn_channels, d.height, d.width), device=dev)
+        self._prior = torch.zeros((capacity, 1, d.n_action), device=dev)
+        self._values = torch.zeros((capacity, 1), device=dev)
+        self.write_idx = 0
+        self._size = 0
+        self.total_written = 0
+
+    def _advance(self, rows: int) -> None:
+        self.write_idx = (self.write_idx + rows) % self.capacity
+        self._size = min(self._size + rows, self.capacity)
+        self.total_written += rows
+
+    def put_games(self, states, pis, zs, augment: bool = True) -> None:
+        """device tensors from Engine.emit_samples: states (n, C*H*W), pis (n, A), zs (n,)"""
+        if not augment:
+            return self.put_batch(states, pis, zs)
+        n = int(states.shape[0])
+        step = max(self.capacity // 8, 1)  # never more than one lap per launch
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            self.e.augment_samples(states[lo:hi].contiguous(), pis[lo:hi].contiguous(), zs[lo:hi].contiguous(),
+                                   out=(self._states, self._prior, self._values), ring_capacity=self.capacity,
+                                   ring_write_idx=self.write_idx)
+            self._advance(8 * (hi - lo))
+
+    def put_batch(self, states, pis, zs) -> None:
+        n = int(states.shape[0])
+        done = 0
+        while done < n:
+            k = min(n - done, self.capacity - self.write_idx)
+            sl = slice(self.write_idx, self.write_idx + k)
+            self._states[sl].view(k, -1).copy_(states[done:done + k].reshape(k, -1))
+            self._prior[sl].view(k, -1).copy_(pis[done:done + k])
+            self._values[sl].view(k).copy_(zs[done:done + k])
+            self._advance(k)
+            done += k
+
+    def sample(self, batch_size: int, timeout=None):
+        if self._size == 0:
+            return None
+        k = min(batch_size, self._size)
+        idxs = torch.randint(0, self._size, (k,), dtype=torch.int64, device=self._states.device)
+        return self._states[idxs].squeeze(1), self._prior[idxs].squeeze(1), self._values[idxs]
+
+    def size(self) -> int:
+        return self._size
+
+    def __len__(self) -> int:
+        return self.capacity

@@ -118,3 +118,48 @@ def test_self_play_many_recycles_slots_and_fills_the_pool():
 
     bp = BatchPool()
     assert arena.self_play_many(20, 1.0, bp)["samples"] == bp.n
+
+
+def test_device_ring_and_learner_close_the_loop():
+    """self-play -> on-device augmentation -> HBM ring -> sample -> the reference's loss, on the GPU"""
+    from alphazero_amd.arena import ChessArena
+    from alphazero_amd.games import TicTacToeGame
+    from alphazero_amd.learner import train_step
+    from alphazero_amd.nets import TicTacToeNet
+    from alphazero_amd.samples import DeviceSampleRing
+
+    torch.manual_seed(0)
+    arena = ChessArena(TicTacToeNet, TicTacToeGame, torch.device("cuda:0"), n_slots=64, num_simulation=20)
+    eng = arena._engine(64)
+    ring = DeviceSampleRing(eng, capacity=3000)
+
+    class Sink:  # what self_play_many feeds: whole finished games, host tensors
+        def put_batch(self, s, p, z):
+            ring.put_games(s.reshape(s.shape[0], -1).cuda(), p.cuda(), z.cuda())
+
+    out = arena.self_play_many(128, 1.0, Sink())
+    assert ring.total_written == 8 * out["samples"] and ring.size() == min(3000, 8 * out["samples"])
+    s, p, z = ring.sample(32)
+    assert s.shape == (32, 9, 3, 3) and p.shape == (32, 9) and z.shape == (32, 1) and s.is_cuda
+    assert torch.allclose(p.sum(1), torch.ones(32, device="cuda"), atol=1e-5)
+    opt = torch.optim.Adam(arena.model.parameters(), lr=1e-3)
+    losses = [train_step(arena.model, opt, ring, 64)[0] for _ in range(60)]
+    assert sum(losses[-10:]) < sum(losses[:10])  # it learns
+    assert not arena.model.training
+
+
+def test_gpu_worker_has_the_reference_worker_signature():
+    import threading
+
+    from alphazero_amd.games import DotsAndBoxesGame
+    from alphazero_amd.nets import DotsAndBoxesNet
+    from alphazero_amd.worker import gpu_self_player_worker
+
+    torch.manual_seed(3)
+    shared = {k: v.clone() for k, v in DotsAndBoxesNet().state_dict().items()}
+    pool = ListPool()
+    gpu_self_player_worker(DotsAndBoxesNet, DotsAndBoxesGame, shared, pool, 12, 0, threading.Lock(), n_slots=8,
+                           num_simulation=10)
+    assert len(pool.items) == 12 * 24  # every dots-and-boxes game has exactly 24 plies
+    st, pi, z = pool.items[0]
+    assert st.shape == (1, 25, 4, 4) and pi.shape == (1, 24) and z.shape == (1,)
