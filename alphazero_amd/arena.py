@@ -85,11 +85,14 @@ class SelfPlayRunner:
             if engine.nn_dtype != torch.bfloat16:
                 raise EngineError("the fused evaluator reads a bf16 batch: create the engine with nn_dtype=torch.bfloat16")
             self.fused = FusedTowerEvaluator(model)
+            if engine.game != GAME_GOMOKU or self.fused.board != engine.dims.height:
+                raise EngineError("the fused evaluator's board does not match the engine's game")
+            self._packed = engine.leaf_buffers()
 
     # one model forward on the gathered batch -> self.logits / self.values (f32, engine device)
     def evaluate(self) -> None:
         if self.fused is not None:
-            _, v = self.fused(self.nn_input, logits_out=self.logits)
+            _, v = self.fused(None, logits_out=self.logits, packed=self._packed, n_boards=self.e.n_slots)
             self.values = v.view(-1)  # handed to expand_backup as is (no copy)
             return
         x = self.nn_input
@@ -123,7 +126,7 @@ class SelfPlayRunner:
 
     def sim_step(self, noise) -> None:
         """one simulation in every active tree: select+gather -> network -> expand+backup"""
-        self.e.select_gather(self.nn_input)
+        self.e.select_gather(None if self.fused is not None else self.nn_input)  # fused: packed leaf batch only
         self.evaluate()
         self.e.expand_backup(self.logits, self.values, noise)
 

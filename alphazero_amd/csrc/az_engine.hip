@@ -3,15 +3,17 @@
 // Data layout in HBM (all owned by the engine, allocated once in az_create):
 //   per tree g (one per game slot), a bump-allocated pool of CHILD RECORDS ("edges"), struct of arrays,
 //   tree-major so that the children of one node are one contiguous, coalesced run:
-//     edgeP   f32  [G][E]   prior of the child (the parent's prior[0, action])
-//     edgeN   i32  [G][E]   child.visits
-//     edgeQ   f64  [G][E]   child.value (running mean, the child's own point of view)
-//     edgeAct u16  [G][E]   action | same_player << 15  (child.player == parent.player)
-//     edgeKid i32  [G][E]   index of the child's own node record once expanded, else -1
-//   node    int2 [G][S+1]   {first edge, number of edges} of every EXPANDED node (node 0 = root)
-//   treeCnt int2 [G]        {nodes used, edges used};  rootN i32 [G], rootQ f64 [G]
+//     edgeQ    f64  [G][E]   child.value (running mean, the child's own point of view)
+//     edgePN   2x32 [G][E]   {prior of the child (the parent's prior[0, action]) f32, child.visits i32}
+//     edgeMeta u32  [G][E]   action (bits 0-8) | child.player == parent.player (bit 9) |
+//                            1 + first edge of the child's own block once it is expanded (bits 10-31)
+//   A node's block holds one record per legal action, and every game here has exactly
+//   PMAX - (moves played) legal actions in a non-terminal position, so a block needs no length field and
+//   there is no node table: the root's block starts at edge 0.
+//   edgeCnt i32 [G] (edges used; 0 = root not expanded);  rootN i32 [G], rootQ f64 [G]
 //   per simulation:  path i32 [G][D] (edge followed at each level), leaf int4 [G]
-//   {depth, kind, value bits, player}, leafState u32 [G][SW]
+//   {depth, kind, value bits, player}, leafRing u32 [G][8][SW] = the leaf's 8-state history as bitboards,
+//   oldest first (entry 7 = the leaf position itself): the packed form of the NN input
 //   per game: the whole trajectory as bitboards, traj u32 [G][PMAX+1][SW] (entry t = position after
 //   t plies; the 8-deep history window of the reference is just entries t-7..t), trajPlayer i8,
 //   trajVisits u16 [G][PMAX][A] (pi is kept as integer visit counts and divided on emission).
@@ -45,20 +47,17 @@ enum : int { KIND_EVAL = 0, KIND_TERMINAL = 1 };
 enum : int { ERR_EDGE_CAP = 1, ERR_NODE_CAP = 2, ERR_DEPTH_CAP = 4, ERR_ILLEGAL = 8, ERR_NO_ROOT = 16 };
 
 struct View {  // kernel argument: raw device pointers + sizes
-  int G, E, NC, D;
+  int G, E, D;
   float c_puct, epsilon;
-  float *edgeP;
-  int32_t *edgeN;
   double *edgeQ;
-  uint16_t *edgeAct;
-  int32_t *edgeKid;
-  int2 *node;
-  int2 *treeCnt;
+  int2 *edgePN;
+  uint32_t *edgeMeta;
+  int32_t *edgeCnt;
   int32_t *rootN;
   double *rootQ;
   int32_t *path;
   int4 *leaf;
-  uint32_t *leafState;
+  uint32_t *leafRing;
   uint32_t *traj;
   int8_t *trajPlayer;
   uint16_t *trajVisits;
@@ -69,6 +68,10 @@ struct View {  // kernel argument: raw device pointers + sizes
   unsigned long long *stat;  // [G][6]
   int32_t *err;
 };
+
+constexpr uint32_t META_ACT = 0x1FFu, META_SAME = 0x200u;
+constexpr int META_KID_SHIFT = 10;
+constexpr int MAX_EDGE_CAP = (1 << 22) - 2;
 
 // ------------------------------------------------------------------------- math helpers -------
 __device__ __forceinline__ float az_expf(float x) {  // x <= 0; same fmaf chain as oracle/az_oracle.c
@@ -172,6 +175,8 @@ __device__ __forceinline__ void load_ring(const uint32_t *tb, int ply, uint32_t 
 // One simulation's descent.  MCTS.search :145-160; MCTSNode.select :59-78 with the dtype chain
 //   puct = f32(q64) + ((f32(c_puct) * P) * f32(sqrt64(N_parent))) / f32(n + 1),   strict '>' (lowest
 // action wins ties), q64 = +child.value if the child has the parent's player else -child.value.
+// One dependent memory round trip per level: the three child streams are read together, and the winner's
+// meta word and visit count travel through the argmax butterfly, so nothing is re-read.
 template <class GT, typename OutT>
 __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
   const int g = blockIdx.x, lane = threadIdx.x;
@@ -180,57 +185,58 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
   __shared__ uint32_t cur[GT::SW];
   const int ply = v.ply[g];
   int pl = v.player[g];
+  const int used = v.edgeCnt[g];
+  int nParent = v.rootN[g];
   const uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
   load_ring<GT>(tb, ply, hist, lane);
   if (lane < GT::SW) cur[lane] = tb[(size_t)ply * GT::SW + lane];
   __syncthreads();
 
   const size_t eb = (size_t)g * v.E;
-  const int2 cnt = v.treeCnt[g];
-  int head = 0, depth = 0, kind = KIND_EVAL, node = 0;
-  int nParent = v.rootN[g];
+  int head = 0, depth = 0, kind = KIND_EVAL, base = 0;
   float tval = 0.0f;
   unsigned long long scanned = 0;
-  if (cnt.x > 0) {
+  if (used > 0) {
     for (;;) {
       if (depth >= v.D) { if (lane == 0) atomicOr(v.err, ERR_DEPTH_CAP); return; }
-      const int2 nd = v.node[(size_t)g * v.NC + node];
+      const int cnt = GT::PMAX - (ply + depth);  // legal actions of a non-terminal position
       const float sqrtN = (float)sqrt((double)nParent);
       float best = -INFINITY;
-      int bestIdx = 0x7fffffff;
-      for (int i = lane; i < nd.y; i += 64) {
-        const size_t e = eb + nd.x + i;
-        const float P = v.edgeP[e];
-        const int n = v.edgeN[e];
+      int bestIdx = 0x7fffffff, bestN = 0;
+      uint32_t bestMeta = 0;
+      for (int i = lane; i < cnt; i += 64) {
+        const size_t e = eb + base + i;
         const double q = v.edgeQ[e];
-        const unsigned act = v.edgeAct[e];
-        const double qs = (act & 0x8000u) ? q : -q;
-        const float u = ((v.c_puct * P) * sqrtN) / (float)(n + 1);
+        const int2 pn = v.edgePN[e];
+        const uint32_t m = v.edgeMeta[e];
+        const double qs = (m & META_SAME) ? q : -q;
+        const float u = ((v.c_puct * __int_as_float(pn.x)) * sqrtN) / (float)(pn.y + 1);
         const float sc = (float)qs + u;
-        if (sc > best) { best = sc; bestIdx = i; }
+        if (sc > best) { best = sc; bestIdx = i; bestMeta = m; bestN = pn.y; }
       }
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
         const float ob = __shfl_xor(best, off, 64);
         const int oi = __shfl_xor(bestIdx, off, 64);
-        if (ob > best || (ob == best && oi < bestIdx)) { best = ob; bestIdx = oi; }
+        const uint32_t om = (uint32_t)__shfl_xor((int)bestMeta, off, 64);
+        const int on = __shfl_xor(bestN, off, 64);
+        if (ob > best || (ob == best && oi < bestIdx)) { best = ob; bestIdx = oi; bestMeta = om; bestN = on; }
       }
       bestIdx = uni(bestIdx);
-      scanned += (unsigned)nd.y;
-      if (bestIdx >= nd.y) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
-      const int el = nd.x + bestIdx;
-      const unsigned act = uni((int)v.edgeAct[eb + el]);
-      const int a = (int)(act & 0x7fffu);
-      const int kid = uni(v.edgeKid[eb + el]);
-      const int nEdge = uni(v.edgeN[eb + el]);
-      if (lane == 0) v.path[(size_t)g * v.D + depth] = el;
+      const uint32_t meta = (uint32_t)uni((int)bestMeta);
+      const int nEdge = uni(bestN);
+      scanned += (unsigned)cnt;
+      if (bestIdx >= cnt) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
+      const int a = (int)(meta & META_ACT);
+      const int kid = (int)(meta >> META_KID_SHIFT);
+      if (lane == 0) v.path[(size_t)g * v.D + depth] = base + bestIdx;
       ++depth;
       const int mover = pl;
       pl = GT::apply(cur, a, mover, lane);
       if (lane < GT::SW) hist[head][lane] = cur[lane];
       head = (head + 1) & 7;
       __syncthreads();
-      if (kid >= 0) { node = kid; nParent = nEdge; continue; }
+      if (kid) { base = kid - 1; nParent = nEdge; continue; }
       const int term = uni(GT::terminal(cur, a, mover, ply + depth, lane));
       if (term != T_NONE) { kind = KIND_TERMINAL; tval = terminal_value(term, pl); }
       break;
@@ -243,8 +249,9 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
     st[3] += (kind == KIND_EVAL); st[4] += (kind == KIND_TERMINAL);
   }
   if (kind == KIND_EVAL) {
-    if (lane < GT::SW) v.leafState[(size_t)g * GT::SW + lane] = cur[lane];
-    write_planes<GT, OutT>(hist, head, pl, nn_input + (size_t)g * (GT::CIN * GT::HW), lane);
+    uint32_t *lr = v.leafRing + (size_t)g * 8 * GT::SW;
+    for (int i = lane; i < 8 * GT::SW; i += 64) lr[i] = hist[(head + i / GT::SW) & 7][i % GT::SW];
+    if (nn_input) write_planes<GT, OutT>(hist, head, pl, nn_input + (size_t)g * (GT::CIN * GT::HW), lane);
   }
 }
 
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
   const int32_t *path = v.path + (size_t)g * v.D;
   double val;
   if (kind == KIND_EVAL) {
-    if (lane < GT::SW) st[lane] = v.leafState[(size_t)g * GT::SW + lane];
+    if (lane < GT::SW) st[lane] = v.leafRing[((size_t)g * 8 + 7) * GT::SW + lane];
     __syncthreads();
     constexpr int A = GT::A, NI = (A + 63) / 64;
     float p[NI];
@@ -297,32 +304,28 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
       acc = acc + x;
     }
     const float tot = wave_sum(acc);
-    const int2 cnt = v.treeCnt[g];
+    const int used = v.edgeCnt[g];
     int nLegal = 0;
     unsigned long long bal[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) { bal[i] = __ballot(lg[i]); nLegal += __popcll(bal[i]); }
-    if (cnt.y + nLegal > v.E) { if (lane == 0) atomicOr(v.err, ERR_EDGE_CAP); return; }
-    if (cnt.x >= v.NC) { if (lane == 0) atomicOr(v.err, ERR_NODE_CAP); return; }
+    if (used + nLegal > v.E) { if (lane == 0) atomicOr(v.err, ERR_EDGE_CAP); return; }
     int off = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int a = lane + 64 * i;
       if (lg[i]) {
         const int pos = off + __popcll(bal[i] & ((1ull << lane) - 1ull));
-        const size_t e = eb + cnt.y + pos;
-        v.edgeP[e] = p[i] / tot;
-        v.edgeN[e] = 0;
+        const size_t e = eb + used + pos;
         v.edgeQ[e] = 0.0;
-        v.edgeAct[e] = (uint16_t)(a | (GT::same_player(st, a) ? 0x8000 : 0));
-        v.edgeKid[e] = -1;
+        v.edgePN[e] = make_int2(__float_as_int(p[i] / tot), 0);
+        v.edgeMeta[e] = (uint32_t)a | (GT::same_player(st, a) ? META_SAME : 0u);
       }
       off += __popcll(bal[i]);
     }
     if (lane == 0) {
-      v.node[(size_t)g * v.NC + cnt.x] = make_int2(cnt.y, nLegal);
-      v.treeCnt[g] = make_int2(cnt.x + 1, cnt.y + nLegal);
-      if (depth > 0) v.edgeKid[eb + path[depth - 1]] = cnt.x;
+      v.edgeCnt[g] = used + nLegal;
+      if (depth > 0) v.edgeMeta[eb + path[depth - 1]] |= (uint32_t)(used + 1) << META_KID_SHIFT;
       v.stat[(size_t)g * 6 + 5] += (unsigned)nLegal;
     }
     val = (double)values[g];  // value.item()
@@ -337,15 +340,16 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
     size_t e = 0;
     if (j < depth) {
       e = eb + path[depth - 1 - j];
-      flip = (v.edgeAct[e] & 0x8000u) == 0u;
+      flip = (v.edgeMeta[e] & META_SAME) == 0u;
     }
     const unsigned long long fm = __ballot(flip);
     if (j < depth) {
       const int below = __popcll(fm & ((1ull << lane) - 1ull));
       const double x = (below & 1) ? -val : val;
-      const int n = v.edgeN[e] + 1;
+      int *np = &v.edgePN[e].y;
+      const int n = *np + 1;
       const double q = v.edgeQ[e];
-      v.edgeN[e] = n;
+      *np = n;
       v.edgeQ[e] = q + (x - q) / (double)n;
     }
     if (__popcll(fm) & 1) val = -val;
@@ -366,15 +370,15 @@ __global__ __launch_bounds__(64) void k_root_policy(View v, float *pi, int32_t *
   __shared__ int edgeOf[A];  // action -> root edge + 1, 0 where the action is illegal
   for (int a = lane; a < A; a += 64) edgeOf[a] = 0;
   __syncthreads();
-  const bool have = v.active[g] && v.treeCnt[g].x > 0;
+  const bool have = v.active[g] && v.edgeCnt[g] > 0;
   const size_t eb = (size_t)g * v.E;
   float tot = 1.0f;
   if (have) {
-    const int2 nd = v.node[(size_t)g * v.NC];
+    const int cnt = GT::PMAX - v.ply[g];
     int s = 0;
-    for (int i = lane; i < nd.y; i += 64) {
-      s += v.edgeN[eb + nd.x + i];
-      edgeOf[v.edgeAct[eb + nd.x + i] & 0x7fffu] = nd.x + i + 1;
+    for (int i = lane; i < cnt; i += 64) {
+      s += v.edgePN[eb + i].y;
+      edgeOf[v.edgeMeta[eb + i] & META_ACT] = i + 1;
     }
     tot = (float)wave_sum_i(s);
   }
@@ -383,10 +387,11 @@ __global__ __launch_bounds__(64) void k_root_policy(View v, float *pi, int32_t *
     const int k = edgeOf[a];
     const size_t e = eb + (k > 0 ? k - 1 : 0);
     const size_t o = (size_t)g * A + a;
-    if (pi) pi[o] = k ? (float)v.edgeN[e] / tot : 0.0f;
-    if (visits) visits[o] = k ? v.edgeN[e] : 0;
+    const int2 pn = k ? v.edgePN[e] : make_int2(0, 0);
+    if (pi) pi[o] = k ? (float)pn.y / tot : 0.0f;
+    if (visits) visits[o] = pn.y;
     if (childQ) childQ[o] = k ? v.edgeQ[e] : 0.0;
-    if (rootPrior) rootPrior[o] = k ? v.edgeP[e] : 0.0f;
+    if (rootPrior) rootPrior[o] = __int_as_float(pn.x);
   }
 }
 
@@ -419,18 +424,17 @@ __global__ __launch_bounds__(64) void k_play_moves(View v, const float *invTao, 
   uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
   if (lane < GT::SW) cur[lane] = tb[(size_t)ply * GT::SW + lane];
   __syncthreads();
-  if (v.treeCnt[g].x == 0 || ply >= GT::PMAX) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
-  const int2 nd = v.node[(size_t)g * v.NC];
+  if (v.edgeCnt[g] == 0 || ply >= GT::PMAX) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
+  const int cnt = GT::PMAX - ply;
   const size_t eb = (size_t)g * v.E;
   int s = 0;
-  for (int i = lane; i < nd.y; i += 64) s += v.edgeN[eb + nd.x + i];
+  for (int i = lane; i < cnt; i += 64) s += v.edgePN[eb + i].y;
   const float tot = (float)wave_sum_i(s);
   const float it = invTao[g];
   float best = -INFINITY;
   int bestA = 0x7fffffff;
-  for (int i = lane; i < nd.y; i += 64) {
-    const size_t e = eb + nd.x + i;
-    const int a = v.edgeAct[e] & 0x7fffu, n = v.edgeN[e];
+  for (int i = lane; i < cnt; i += 64) {
+    const int a = (int)(v.edgeMeta[eb + i] & META_ACT), n = v.edgePN[eb + i].y;
     vis[a] = (uint16_t)n;
     const float pi = (float)n / tot;
     const float q = az_powf(pi, it) / expo[(size_t)g * A + a];
@@ -557,7 +561,7 @@ __global__ void k_reset_games(View v, const uint8_t *mask) {
   v.player[g] = 1;
   v.active[g] = 1;
   v.result[g] = 0.0f;
-  v.treeCnt[g] = make_int2(0, 0);
+  v.edgeCnt[g] = 0;
   v.rootN[g] = 0;
   v.rootQ[g] = 0.0;
 }
@@ -565,7 +569,7 @@ __global__ void k_reset_games(View v, const uint8_t *mask) {
 __global__ void k_begin_search(View v) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= v.G) return;
-  v.treeCnt[g] = make_int2(0, 0);
+  v.edgeCnt[g] = 0;
   v.rootN[g] = 0;
   v.rootQ[g] = 0.0;
 }
@@ -685,7 +689,13 @@ int az_create(const az_config *cfg, az_engine **out) {
   d.n_slots = cfg->n_slots;
   d.node_cap = cfg->max_sims + 1;
   const long long worst = (long long)cfg->max_sims * A;
-  d.edge_cap = (int)(cfg->edge_cap > 0 ? (long long)cfg->edge_cap : worst);
+  const long long want = cfg->edge_cap > 0 ? (long long)cfg->edge_cap : worst;
+  if (want > MAX_EDGE_CAP) {
+    g_create_err = "edge_cap (max_sims * A by default) exceeds the 22-bit child-block pointer: at most " + std::to_string(MAX_EDGE_CAP);
+    delete e;
+    return AZ_EINVAL;
+  }
+  d.edge_cap = (int)want;
   if (d.edge_cap < A) d.edge_cap = A;
   d.depth_cap = (cfg->max_sims < d.max_plies ? cfg->max_sims : d.max_plies) + 1;
   e->nin = d.nn_channels * d.height * d.width;
@@ -693,7 +703,7 @@ int az_create(const az_config *cfg, az_engine **out) {
 
   View &v = e->v;
   memset(&v, 0, sizeof(v));
-  v.G = d.n_slots; v.E = d.edge_cap; v.NC = d.node_cap; v.D = d.depth_cap;
+  v.G = d.n_slots; v.E = d.edge_cap; v.D = d.depth_cap;
   v.c_puct = cfg->c_puct; v.epsilon = cfg->epsilon;
   const size_t G = (size_t)d.n_slots, E = (size_t)d.edge_cap;
   int64_t total = 0;
@@ -706,18 +716,15 @@ int az_create(const az_config *cfg, az_engine **out) {
     total += (int64_t)bytes;
     return p;
   };
-  v.edgeP = (float *)alloc(G * E * sizeof(float));
-  v.edgeN = (int32_t *)alloc(G * E * sizeof(int32_t));
   v.edgeQ = (double *)alloc(G * E * sizeof(double));
-  v.edgeAct = (uint16_t *)alloc(G * E * sizeof(uint16_t));
-  v.edgeKid = (int32_t *)alloc(G * E * sizeof(int32_t));
-  v.node = (int2 *)alloc(G * (size_t)d.node_cap * sizeof(int2));
-  v.treeCnt = (int2 *)alloc(G * sizeof(int2));
+  v.edgePN = (int2 *)alloc(G * E * sizeof(int2));
+  v.edgeMeta = (uint32_t *)alloc(G * E * sizeof(uint32_t));
+  v.edgeCnt = (int32_t *)alloc(G * sizeof(int32_t));
   v.rootN = (int32_t *)alloc(G * sizeof(int32_t));
   v.rootQ = (double *)alloc(G * sizeof(double));
   v.path = (int32_t *)alloc(G * (size_t)d.depth_cap * sizeof(int32_t));
   v.leaf = (int4 *)alloc(G * sizeof(int4));
-  v.leafState = (uint32_t *)alloc(G * (size_t)d.state_words * sizeof(uint32_t));
+  v.leafRing = (uint32_t *)alloc(G * 8 * (size_t)d.state_words * sizeof(uint32_t));
   v.traj = (uint32_t *)alloc(G * (size_t)(d.max_plies + 1) * d.state_words * sizeof(uint32_t));
   v.trajPlayer = (int8_t *)alloc(G * (size_t)(d.max_plies + 1));
   v.trajVisits = (uint16_t *)alloc(G * (size_t)d.max_plies * A * sizeof(uint16_t));
@@ -774,7 +781,6 @@ int az_check(az_engine *e, void *stream) {
   if (flag) {
     e->err = "device error flags:";
     if (flag & ERR_EDGE_CAP) e->err += " edge pool exhausted (raise edge_cap/max_sims)";
-    if (flag & ERR_NODE_CAP) e->err += " node pool exhausted (more simulations than max_sims)";
     if (flag & ERR_DEPTH_CAP) e->err += " path deeper than depth_cap";
     if (flag & ERR_ILLEGAL) e->err += " illegal move";
     if (flag & ERR_NO_ROOT) e->err += " root not expanded / no child to select";
@@ -819,11 +825,11 @@ int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32
   }
   const int32_t one_ply = ply, one_player = root_player;
   const uint8_t act = 1;
-  const int2 zero = make_int2(0, 0);
+  const int32_t zero = 0;
   AZ_HIP(hipMemcpyAsync(e->v.ply + slot, &one_ply, sizeof(int32_t), hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.player + slot, &one_player, sizeof(int32_t), hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.active + slot, &act, 1, hipMemcpyHostToDevice, s));
-  AZ_HIP(hipMemcpyAsync(e->v.treeCnt + slot, &zero, sizeof(int2), hipMemcpyHostToDevice, s));
+  AZ_HIP(hipMemcpyAsync(e->v.edgeCnt + slot, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s));
   AZ_HIP(hipStreamSynchronize(s));  // host staging buffers die here
   return AZ_OK;
 }
@@ -835,8 +841,15 @@ int az_begin_search(az_engine *e, void *stream) {
   return launch_check(e, "k_begin_search");
 }
 
+int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf_dev) {
+  if (!e) return AZ_EINVAL;
+  if (ring_dev) *ring_dev = e->v.leafRing;
+  if (leaf_dev) *leaf_dev = e->v.leaf;
+  return AZ_OK;
+}
+
 int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
-  if (!e || !nn_input_dev) return AZ_EINVAL;
+  if (!e) return AZ_EINVAL;
   const dim3 grid(e->v.G), block(64);
   hipStream_t s = (hipStream_t)stream;
   switch (e->cfg.nn_dtype) {

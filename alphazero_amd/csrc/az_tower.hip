@@ -164,7 +164,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 // wl: [L][9][4][2][64][8] bf16.  bias: [1+L][64] f32.  headw: [3][64] f32 (policy, value0, value1),
 // headb: [3].  pfeat: (G, NV) f32, vfeat: (G, 2, NV) f32 (= the inputs of the heads' Linear layers).
 template <int N, int BPW>
-__global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const uint16_t *__restrict__ x, int G, const char *__restrict__ w0,
+__global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
+                                               const int4 *__restrict__ leafrec, int G, const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
                                                float *__restrict__ pfeat, float *__restrict__ vfeat) {
@@ -173,6 +174,8 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   char *act = smem;
   char *wbuf = smem + Q::ACT_BYTES;
   float *hw = (float *)(wbuf + 2 * STAGE_BYTES);  // 3*64 + 3 floats
+  uint32_t *rg = (uint32_t *)(wbuf + 2 * STAGE_BYTES + 1024);  // packed input: BPW x 8 states x SWB words
+  constexpr int WC = (Q::NV + 31) / 32, SWB = 2 * WC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   for (int i = tid; i < Q::ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero slot
@@ -200,14 +203,34 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
 
   const int ngroups = (G + BPW - 1) / BPW;
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    // ---- input: NCHW bf16 rows -> act[pos][0..15] (channels 9..15 zero)
+    // ---- input -> act[cell][0..15] (channels 9..15 zero): either the NCHW bf16 planes, or the engine's packed
+    // leaf batch (8 bitboard states per board + the player in the leaf record), expanded here
+    if (x == nullptr) {
+      for (int i = tid; i < BPW * 8 * SWB; i += 256) {
+        const int g = grp * BPW + i / (8 * SWB);
+        rg[i] = g < G ? ring[(size_t)g * 8 * SWB + i % (8 * SWB)] : 0u;
+      }
+      __syncthreads();
+    }
     for (int m = tid; m < Q::NVT; m += 256) {
       const int b = m / Q::NV, cell = m % Q::NV, g = grp * BPW + b;
       uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (g < G) {
-        const uint16_t *xr = x + (size_t)g * 9 * Q::NV + cell;
+        if (x != nullptr) {
+          const uint16_t *xr = x + (size_t)g * 9 * Q::NV + cell;
 #pragma unroll
-        for (int ch = 0; ch < 9; ++ch) c[ch >> 1] |= (uint32_t)xr[ch * Q::NV] << ((ch & 1) * 16);
+          for (int ch = 0; ch < 9; ++ch) c[ch >> 1] |= (uint32_t)xr[ch * Q::NV] << ((ch & 1) * 16);
+        } else {
+          const uint32_t *rb = rg + b * 8 * SWB;
+          const int wi = cell >> 5, sh = cell & 31;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {  // +1 -> 0x3F80, -1 -> 0xBF80 (bf16)
+            const uint32_t mine = (rb[k * SWB + wi] >> sh) & 1u, theirs = (rb[k * SWB + WC + wi] >> sh) & 1u;
+            const uint32_t v = mine ? 0x3F80u : (theirs ? 0xBF80u : 0u);
+            c[k >> 1] |= v << ((k & 1) * 16);
+          }
+          c[4] = leafrec[g].w > 0 ? 0x3F80u : 0xBF80u;
+        }
       }
       *(uint4 *)(act + act_addr(m, 0)) = make_uint4(c[0], c[1], c[2], c[3]);
       *(uint4 *)(act + act_addr(m, 1)) = make_uint4(c[4], c[5], c[6], c[7]);
@@ -275,29 +298,31 @@ extern "C" {
 const char *az_tower_last_error(void) { return g_tower_err.c_str(); }
 
 int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
-                     const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
+                     const void *packed_ring_dev, const void *packed_leaf_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
                      const float *headb_dev, float *pfeat_dev, float *vfeat_dev, void *stream) {
   using namespace aztower;
-  if (!x_bf16_dev || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !pfeat_dev || !vfeat_dev ||
+  if ((!x_bf16_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !pfeat_dev || !vfeat_dev ||
       (n_conv_layers > 0 && !wl_dev)) { g_tower_err = "null argument"; return AZ_EINVAL; }
   if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1)) { g_tower_err = "n_boards >= 1, even n_conv_layers"; return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   hipError_t err;
   if (board_size == 15) {
     constexpr int BPW = 1;
-    const size_t lds = Geo<15, BPW>::ACT_BYTES + 2 * STAGE_BYTES + 1024;
+    const size_t lds = Geo<15, BPW>::ACT_BYTES + 2 * STAGE_BYTES + 1024 + 2048;
     static bool attr15 = false;
     if (!attr15) { (void)hipFuncSetAttribute((const void *)k_tower<15, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr15 = true; }
     const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 256 * AZ_TOWER_WAVES_PER_SIMD ? groups : 256 * AZ_TOWER_WAVES_PER_SIMD;
-    hipLaunchKernelGGL((k_tower<15, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, n_boards, (const char *)w0_dev,
+    hipLaunchKernelGGL((k_tower<15, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
+                       (const int4 *)packed_leaf_dev, n_boards, (const char *)w0_dev,
                        (const char *)wl_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
   } else if (board_size == 9) {
     constexpr int BPW = 3;
-    const size_t lds = Geo<9, BPW>::ACT_BYTES + 2 * STAGE_BYTES + 1024;
+    const size_t lds = Geo<9, BPW>::ACT_BYTES + 2 * STAGE_BYTES + 1024 + 2048;
     static bool attr9 = false;
     if (!attr9) { (void)hipFuncSetAttribute((const void *)k_tower<9, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr9 = true; }
     const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 256 * AZ_TOWER_WAVES_PER_SIMD ? groups : 256 * AZ_TOWER_WAVES_PER_SIMD;
-    hipLaunchKernelGGL((k_tower<9, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, n_boards, (const char *)w0_dev,
+    hipLaunchKernelGGL((k_tower<9, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
+                       (const int4 *)packed_leaf_dev, n_boards, (const char *)w0_dev,
                        (const char *)wl_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
   } else {
     g_tower_err = "board_size must be 9 or 15";

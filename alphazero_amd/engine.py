@@ -40,7 +40,7 @@ class AzStats(C.Structure):
 EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check", "az_reset_games",
            "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_root_policy",
            "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
-           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_augment_samples"]
+           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_augment_samples", "az_leaf_buffers"]
 
 _lib = None
 
@@ -77,7 +77,8 @@ def load_library() -> C.CDLL:
     lib.az_reset_stats.argtypes = [vp, vp]
     lib.az_eval_hash.argtypes = [vp, vp, C.c_float, vp, vp, vp]
     lib.az_augment_samples.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
-    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.az_leaf_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
     for name in EXPORTS:
@@ -199,7 +200,14 @@ class Engine:
     def begin_search(self):
         self._ck(self.lib.az_begin_search(self._h, self._stream()))
 
-    def select_gather(self, nn_input):
+    def leaf_buffers(self):
+        """device addresses (ints) of the packed leaf batch: (ring u32 (G,8,SW), leaf records int32 (G,4))"""
+        ring, leaf = C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.az_leaf_buffers(self._h, C.byref(ring), C.byref(leaf)))
+        return ring.value, leaf.value
+
+    def select_gather(self, nn_input=None):
+        """nn_input None: only the packed leaf batch is produced (what the fused tower reads)"""
         d = self.dims
         self._expect(nn_input, (self.n_slots, d.nn_channels, d.height, d.width), self.nn_dtype, "nn_input")
         self._ck(self.lib.az_select_gather(self._h, _ptr(nn_input), self._stream()))

@@ -88,15 +88,25 @@ class FusedTowerEvaluator:
         self.v1_wt, self.v1_b = f(v1.weight).t().contiguous(), f(v1.bias)
         self.v2_wt, self.v2_b = f(v2.weight).t().contiguous(), f(v2.bias)
 
-    def __call__(self, x: torch.Tensor, logits_out: torch.Tensor | None = None):
-        if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
-            raise EngineError("FusedTowerEvaluator expects a contiguous (B,9,N,N) bf16 batch on the model's GPU")
-        B = x.shape[0]
+    def __call__(self, x: torch.Tensor | None, logits_out: torch.Tensor | None = None, packed=None, n_boards: int = 0):
+        """x: contiguous (B,9,N,N) bf16 batch, or None with packed=(ring_ptr, leaf_ptr) from Engine.leaf_buffers()
+        and n_boards = the engine's slot count (the packed leaf batch is read straight from the engine)."""
+        if x is not None:
+            if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
+                raise EngineError("FusedTowerEvaluator expects a contiguous (B,9,N,N) bf16 batch on the model's GPU")
+            B = x.shape[0]
+            ring_p = leaf_p = None
+        else:
+            if packed is None or n_boards < 1:
+                raise EngineError("FusedTowerEvaluator: give either x or packed=(ring, leaf) with n_boards")
+            B = n_boards
+            ring_p, leaf_p = C.c_void_p(packed[0]), C.c_void_p(packed[1])
         if B not in self._buf:
             self._buf[B] = (torch.empty(B, self.n2, device=self.device), torch.empty(B, 2 * self.n2, device=self.device))
         pfeat, vfeat = self._buf[B]
         P = lambda t: C.c_void_p(t.data_ptr())
-        rc = self.lib.az_tower_forward(self.board, B, self.n_layers, P(x), P(self.w0), P(self.wl), P(self.bias),
+        rc = self.lib.az_tower_forward(self.board, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
+                                       P(self.w0), P(self.wl), P(self.bias),
                                        P(self.headw), P(self.headb), P(pfeat), P(vfeat),
                                        C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:

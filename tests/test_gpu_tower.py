@@ -54,3 +54,40 @@ def test_fused_tower_rejects_other_nets():
 
     assert not FusedTowerEvaluator.supports(TicTacToeNet())
     assert not FusedTowerEvaluator.supports(GomokuNet(15, 128, 2))
+
+
+@pytest.mark.parametrize("board", [15, 9])
+def test_packed_leaf_batch_equals_dense_planes(board):
+    """The tower fed from the engine's packed leaf batch (bitboards) == fed from the dense bf16 planes."""
+    from alphazero_amd import Engine
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(0)
+    G, sims = 200, 12
+    net = _randomised(GomokuNet(board, 64, 2)).eval().cuda()
+    ev = FusedTowerEvaluator(net)
+    eng = Engine(2, G, sims, board_size=board, nn_dtype=torch.bfloat16, device="cuda:0")
+    nn = eng.new_nn_input()
+    A = board * board
+    logits, values = eng.new(G, A), eng.new(G)
+    # play a few moves so that histories are non-trivial, then compare on a mid-search leaf batch
+    it = torch.ones(G, device="cuda")
+    for _ in range(5):
+        eng.begin_search()
+        for _ in range(sims):
+            eng.select_gather(nn)
+            eng.eval_hash(nn, logits, values, 6.0)
+            eng.expand_backup(logits, values, None)
+        eng.play_moves(it, torch.empty(G, A, device="cuda").exponential_(1))
+    eng.begin_search()
+    for _ in range(6):
+        eng.select_gather(nn)
+        eng.eval_hash(nn, logits, values, 6.0)
+        eng.expand_backup(logits, values, None)
+    eng.select_gather(nn)
+    p1, v1 = ev(nn)
+    p1, v1 = p1.clone(), v1.clone()
+    p2, v2 = ev(None, packed=eng.leaf_buffers(), n_boards=G)
+    eng.check()
+    assert torch.equal(p1, p2) and torch.equal(v1, v2)
