@@ -48,8 +48,8 @@ __device__ __forceinline__ int act_addr(int p, int chunk) { return p * 128 + ((c
 template <int N, int BPW>
 struct Geo {
   static constexpr int NV = N * N, NVT = BPW * NV;
-  static constexpr int ZERO_OFF = NVT * 128;       // 16 zero bytes (padded to 256)
-  static constexpr int ACT_BYTES = NVT * 128 + 256;
+  static constexpr int ZERO_OFF = NVT * 128;       // 16 zero bytes
+  static constexpr int ACT_BYTES = NVT * 128 + 16;
   static_assert(NVT <= 256, "8 position tiles of 32");
 };
 
@@ -62,9 +62,13 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 #ifndef AZ_TOWER_STAGE_TAPS
 #define AZ_TOWER_STAGE_TAPS 3  // taps staged per barrier: 3 = one kernel row (48 KiB of LDS), 1 = one tap (16 KiB)
 #endif
+#ifndef AZ_TOWER_ABLATE
+#define AZ_TOWER_ABLATE 0  // 0 = product; 1 / 2 = timing diagnostics only (wrong results)
+#endif
 #ifndef AZ_TOWER_WAVES_PER_SIMD
 #define AZ_TOWER_WAVES_PER_SIMD 2
 #endif
+constexpr int HW_BYTES = 784, RG_BYTES = 640;  // head weights (3*64+3 floats); one packed-input staging buffer
 constexpr int ST = AZ_TOWER_STAGE_TAPS;
 constexpr int STAGE_BYTES = ST * TAP_BYTES;
 
@@ -80,21 +84,23 @@ __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave,
 
 // one conv layer, in registers: acc[pt][ct] += W * X.  KS = 16-channel k-steps per tap (1 or 4).
 // pp[pt] = this lane's cell, vm[pt] = bit t set when tap t of that cell is on the board.
-// Weights are staged ST taps at a time, double buffered: 9/ST barriers per layer.
-template <int KS, int N, int ZERO_OFF>
-__device__ __forceinline__ void conv_layer(const char *act, char *wbuf, const char *wg, int tid, int lane,
-                                           const int (&pp)[2], const uint32_t (&vm)[2], f32x16 (&acc)[2][2]) {
+// Weights are staged ST taps at a time, double buffered (9/ST barriers per layer).  On entry stage 0 of THIS
+// layer is already in buffer `buf` (landed and barriered); during the last stage the first stage of the NEXT
+// layer (wnext, KSN k-steps per tap; nullptr = none) is prefetched, so no layer starts with an exposed DMA.
+template <int KS, int KSN, int N, int ZERO_OFF>
+__device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext,
+                                           int tid, int lane, const int (&pp)[2], const uint32_t (&vm)[2],
+                                           f32x16 (&acc)[2][2]) {
   constexpr int TB = KS * 2048;  // bytes per tap
   constexpr int NSTAGE = 9 / ST;
   const int h = lane >> 5, r = lane & 31, wave = tid >> 6;
-  stage_w<KS>(wg, wbuf, wave, lane);  // stage 0 -> buffer 0
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 #pragma unroll 1
   for (int sg = 0; sg < NSTAGE; ++sg) {
     // the DMA of the next stage's weights runs under this stage's MFMAs
-    if (sg < NSTAGE - 1) stage_w<KS>(wg + (sg + 1) * ST * TB, wbuf + ((sg + 1) & 1) * STAGE_BYTES, wave, lane);
-    const char *wst = wbuf + (sg & 1) * STAGE_BYTES;
+    char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
+    if (sg < NSTAGE - 1) stage_w<KS>(wg + (sg + 1) * ST * TB, wn, wave, lane);
+    else if (wnext != nullptr) stage_w<KSN>(wnext, wn, wave, lane);
+    const char *wst = wbuf + ((buf + sg) & 1) * STAGE_BYTES;
 #pragma unroll
     for (int j = 0; j < ST; ++j) {
       const int tap = sg * ST + j;
@@ -111,19 +117,34 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, const ch
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int chunk = ks * 2 + h;
+#if AZ_TOWER_ABLATE == 2  // diagnostic build: MFMAs on register operands, no LDS fragment reads
+        bf16x8 a0, a1;
+        for (int z = 0; z < 8; ++z) { a0[z] = (__bf16)(float)(chunk + z); a1[z] = (__bf16)(float)(r + z); }
+#else
         const bf16x8 a0 = *(const bf16x8 *)(wc + chunk * 1024 + r * 16);
         const bf16x8 a1 = *(const bf16x8 *)(wc + chunk * 1024 + 512 + r * 16);
+#endif
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
+#if AZ_TOWER_ABLATE == 2
+          bf16x8 b = a0;
+          b[0] = (__bf16)(float)(q[pt] + sw[pt]);
+#else
           const bf16x8 b = *(const bf16x8 *)(act + (on[pt] ? q[pt] + ((chunk ^ sw[pt]) << 4) : ZERO_OFF));
+#endif
+#if AZ_TOWER_ABLATE == 1  // diagnostic build: LDS fragment reads kept alive, no MFMAs
+          asm volatile("" ::"v"(a0), "v"(a1), "v"(b));
+#else
           acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[pt][0], 0, 0, 0);
           acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[pt][1], 0, 0, 0);
+#endif
         }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next stage has landed
     __syncthreads();  // after the last stage: every wave has finished reading act -> the epilogue may overwrite it
   }
+  buf = (buf + NSTAGE) & 1;
 }
 
 // bias (+ residual) + ReLU, bf16, written back in place
@@ -160,9 +181,16 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 }
 
-// x: (G, 9, N, N) bf16.  w0: [9][1][2][64][8] bf16 (first conv, 9 input channels padded to 16).
-// wl: [L][9][4][2][64][8] bf16.  bias: [1+L][64] f32.  headw: [3][64] f32 (policy, value0, value1),
-// headb: [3].  pfeat: (G, NV) f32, vfeat: (G, 2, NV) f32 (= the inputs of the heads' Linear layers).
+// async global -> LDS copy of 4 B per lane
+__device__ __forceinline__ void glds4(const void *g_lane, void *lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
+                                   (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)lds_base, 4, 0, 0);
+}
+
+// x: (G, 9, N, N) bf16, or nullptr to read the engine's packed leaf batch (ring u32 (G,8,SWB) + leaf records).
+// w0: [9][1][2][64][8] bf16 (first conv, 9 input channels padded to 16).  wl: [L][9][4][2][64][8] bf16.
+// bias: [1+L][64] f32.  headw: [3][64] f32 (policy, value0, value1), headb: [3].
+// pfeat: (G, NV) f32, vfeat: (G, 2, NV) f32 (= the inputs of the heads' Linear layers).
 template <int N, int BPW>
 __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
                                                const int4 *__restrict__ leafrec, int G, const char *__restrict__ w0,
@@ -170,16 +198,20 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
                                                const float *__restrict__ headw, const float *__restrict__ headb,
                                                float *__restrict__ pfeat, float *__restrict__ vfeat) {
   using Q = Geo<N, BPW>;
+  constexpr int WC = (Q::NV + 31) / 32, SWB = 2 * WC, RGW = BPW * 8 * SWB;  // packed input words per group
+  constexpr int RG_STRIDE = RG_BYTES;                                       // bytes per input buffer (>= RGW*4 + 4*BPW)
+  static_assert(RGW * 4 + 4 * BPW <= RG_BYTES, "input staging buffer too small");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *act = smem;
   char *wbuf = smem + Q::ACT_BYTES;
   float *hw = (float *)(wbuf + 2 * STAGE_BYTES);  // 3*64 + 3 floats
-  uint32_t *rg = (uint32_t *)(wbuf + 2 * STAGE_BYTES + 1024);  // packed input: BPW x 8 states x SWB words
-  constexpr int WC = (Q::NV + 31) / 32, SWB = 2 * WC;
+  char *rgb = wbuf + 2 * STAGE_BYTES + HW_BYTES;  // 2 x {RGW ring words, BPW player words}
+  float *bl = (float *)(rgb + 2 * RG_STRIDE);     // (1+L)*64 biases
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   for (int i = tid; i < Q::ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero slot
   for (int i = tid; i < 3 * CH + 3; i += 256) hw[i] = i < 3 * CH ? headw[i] : headb[i - 3 * CH];
+  for (int i = tid; i < (1 + L) * CH; i += 256) bl[i] = bias[i];
 
   // this lane's two cells (B-operand column / accumulator column): tile = 2*wave + pt
   int pp[2];
@@ -199,19 +231,30 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     }
     vm[pt] = ok[pt] ? mask : 0u;
   }
-  __syncthreads();
 
   const int ngroups = (G + BPW - 1) / BPW;
+  // DMA of one group's packed input (ring words + players) into input buffer `which` (wave 0 only)
+  auto stage_input = [&](int grp, int which) {
+    if (wave != 0 || x != nullptr) return;
+    const int nb = min(BPW, G - grp * BPW);
+    char *dst = rgb + which * RG_STRIDE;
+    if (lane * 16 < nb * 8 * SWB * 4) glds16((const char *)(ring + (size_t)grp * RGW) + lane * 16, dst);
+    if (lane < nb) glds4(&leafrec[grp * BPW + lane].w, dst + RGW * 4);
+  };
+  int buf = 0, inb = 0;
+  if (blockIdx.x < ngroups) {  // prologue: the stem's first weight stage and the first group's input
+    stage_w<1>(w0, wbuf, wave, lane);
+    stage_input(blockIdx.x, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    // ---- input -> act[cell][0..15] (channels 9..15 zero): either the NCHW bf16 planes, or the engine's packed
-    // leaf batch (8 bitboard states per board + the player in the leaf record), expanded here
-    if (x == nullptr) {
-      for (int i = tid; i < BPW * 8 * SWB; i += 256) {
-        const int g = grp * BPW + i / (8 * SWB);
-        rg[i] = g < G ? ring[(size_t)g * 8 * SWB + i % (8 * SWB)] : 0u;
-      }
-      __syncthreads();
-    }
+    const bool has_next = grp + (int)gridDim.x < ngroups;
+    if (has_next) stage_input(grp + gridDim.x, inb ^ 1);  // lands under this group's tower
+    // ---- input -> act[cell][0..15] (channels 9..15 zero): the NCHW bf16 planes, or the packed leaf batch
+    // (8 bitboard states per board + the player to move), expanded here
+    const uint32_t *rg = (const uint32_t *)(rgb + inb * RG_STRIDE);
     for (int m = tid; m < Q::NVT; m += 256) {
       const int b = m / Q::NV, cell = m % Q::NV, g = grp * BPW + b;
       uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -229,20 +272,22 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
             const uint32_t v = mine ? 0x3F80u : (theirs ? 0xBF80u : 0u);
             c[k >> 1] |= v << ((k & 1) * 16);
           }
-          c[4] = leafrec[g].w > 0 ? 0x3F80u : 0xBF80u;
+          c[4] = (int)rg[RGW + b] > 0 ? 0x3F80u : 0xBF80u;
         }
       }
       *(uint4 *)(act + act_addr(m, 0)) = make_uint4(c[0], c[1], c[2], c[3]);
       *(uint4 *)(act + act_addr(m, 1)) = make_uint4(c[4], c[5], c[6], c[7]);
     }
+    inb ^= 1;
     __syncthreads();
 
     f32x16 acc[2][2];
     uint2 res[2][2][4];
     // ---- stem
     zero_acc(acc);
-    conv_layer<1, N, Q::ZERO_OFF>(act, wbuf, w0, tid, lane, pp, vm, acc);
-    epilogue<false>(act, bias, lane, pp, ok, acc, res);
+    if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
+    else conv_layer<1, 1, N, Q::ZERO_OFF>(act, wbuf, buf, w0, has_next ? w0 : nullptr, tid, lane, pp, vm, acc);
+    epilogue<false>(act, bl, lane, pp, ok, acc, res);
     __syncthreads();
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
@@ -254,23 +299,28 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
 #pragma unroll
           for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pp[pt], ct * 4 + q) + 8 * h);
       zero_acc(acc);
-      conv_layer<4, N, Q::ZERO_OFF>(act, wbuf, wl + (size_t)l * 9 * TAP_BYTES, tid, lane, pp, vm, acc);
-      epilogue<false>(act, bias + (1 + l) * CH, lane, pp, ok, acc, res);
+      conv_layer<4, 4, N, Q::ZERO_OFF>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
+                                       lane, pp, vm, acc);
+      epilogue<false>(act, bl + (1 + l) * CH, lane, pp, ok, acc, res);
       __syncthreads();
       zero_acc(acc);
-      conv_layer<4, N, Q::ZERO_OFF>(act, wbuf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid, lane, pp, vm, acc);
-      epilogue<true>(act, bias + (2 + l) * CH, lane, pp, ok, acc, res);
+      if (l + 2 < L)
+        conv_layer<4, 4, N, Q::ZERO_OFF>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
+                                         tid, lane, pp, vm, acc);
+      else  // last layer of this board: prefetch the next board's stem weights
+        conv_layer<4, 1, N, Q::ZERO_OFF>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, has_next ? w0 : nullptr, tid, lane,
+                                         pp, vm, acc);
+      epilogue<true>(act, bl + (2 + l) * CH, lane, pp, ok, acc, res);
       __syncthreads();
     }
     // ---- heads: 1x1 convs (+folded BN) + ReLU, one position per thread
     for (int m = tid; m < Q::NVT; m += 256) {
       const int b = m / Q::NV, cell = m % Q::NV, g = grp * BPW + b;
       if (g >= G) continue;
-      const int p = m;
       float s0 = hw[3 * CH + 0], s1 = hw[3 * CH + 1], s2 = hw[3 * CH + 2];
 #pragma unroll
       for (int chunk = 0; chunk < 8; ++chunk) {
-        const uint4 u = *(const uint4 *)(act + act_addr(p, chunk));
+        const uint4 u = *(const uint4 *)(act + act_addr(m, chunk));
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -285,7 +335,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
       vfeat[((size_t)g * 2 + 0) * Q::NV + cell] = fmaxf(s1, 0.0f);
       vfeat[((size_t)g * 2 + 1) * Q::NV + cell] = fmaxf(s2, 0.0f);
     }
-    __syncthreads();  // heads done reading before the next group's input lands
+    __syncthreads();  // heads done reading before the next group's input overwrites act
   }
 }
 
@@ -308,18 +358,18 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
   hipError_t err;
   if (board_size == 15) {
     constexpr int BPW = 1;
-    const size_t lds = Geo<15, BPW>::ACT_BYTES + 2 * STAGE_BYTES + 1024 + 2048;
-    static bool attr15 = false;
-    if (!attr15) { (void)hipFuncSetAttribute((const void *)k_tower<15, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr15 = true; }
+    const size_t lds = Geo<15, BPW>::ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + (size_t)(1 + n_conv_layers) * CH * 4;
+    if (lds > 160 * 1024) { g_tower_err = "too many layers for the LDS bias table"; return AZ_EINVAL; }
+    (void)hipFuncSetAttribute((const void *)k_tower<15, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 256 * AZ_TOWER_WAVES_PER_SIMD ? groups : 256 * AZ_TOWER_WAVES_PER_SIMD;
     hipLaunchKernelGGL((k_tower<15, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
                        (const int4 *)packed_leaf_dev, n_boards, (const char *)w0_dev,
                        (const char *)wl_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
   } else if (board_size == 9) {
     constexpr int BPW = 3;
-    const size_t lds = Geo<9, BPW>::ACT_BYTES + 2 * STAGE_BYTES + 1024 + 2048;
-    static bool attr9 = false;
-    if (!attr9) { (void)hipFuncSetAttribute((const void *)k_tower<9, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr9 = true; }
+    const size_t lds = Geo<9, BPW>::ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + (size_t)(1 + n_conv_layers) * CH * 4;
+    if (lds > 160 * 1024) { g_tower_err = "too many layers for the LDS bias table"; return AZ_EINVAL; }
+    (void)hipFuncSetAttribute((const void *)k_tower<9, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 256 * AZ_TOWER_WAVES_PER_SIMD ? groups : 256 * AZ_TOWER_WAVES_PER_SIMD;
     hipLaunchKernelGGL((k_tower<9, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
                        (const int4 *)packed_leaf_dev, n_boards, (const char *)w0_dev,

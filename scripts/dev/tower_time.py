@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '/root/repo')
 from alphazero_amd.nets import GomokuNet
 from alphazero_amd.fused import FusedTowerEvaluator
 torch.manual_seed(0)

@@ -8,7 +8,10 @@ import os
 import sys
 from collections import defaultdict
 
+import json
+
 root = sys.argv[1]
+summary = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(root, counter, "**", "*counter_collection.csv"), recursive=True)
     acc = defaultdict(lambda: [0, 0.0])
@@ -23,5 +26,11 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     for name, (n, tot) in sorted(acc.items()):
         mean_kb = tot / max(n, 1)
         corr = 2.0 if counter == "FETCH_SIZE" else 1.0
+        key = "k_select_gather" if "k_select_gather" in name else ("k_expand_backup" if "k_expand_backup" in name else name)
+        summary.setdefault(key, {})[counter] = {"dispatches": n, "raw_bytes_per_launch": mean_kb * 1e3,
+                                                "corrected_bytes_per_launch": mean_kb * corr * 1e3, "correction": corr}
         print(f"{counter:10s} {name:60s} dispatches={n:6d} mean={mean_kb:12.1f} kB/launch  "
               f"-> {mean_kb * 1e3 / 1e6:9.2f} MB raw, {mean_kb * corr * 1e3 / 1e6:9.2f} MB corrected(x{corr:g})")
+
+with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
+    json.dump(summary, fh, indent=1)
