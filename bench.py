@@ -296,6 +296,18 @@ def main():
         exp_bytes = (st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 20.0 * st["expanded_edges"]
                      + 32.0 * st["sum_depth"] + 36.0 * st["sims"]) / launches
         dom = ("k_select_gather", sel_bytes, sel_ms) if sel_ms >= exp_ms else ("k_expand_backup", exp_bytes, exp_ms)
+        # HBM traffic from PMC counters cannot be collected inside this run (separate rocprofv3 --pmc passes,
+        # scripts/pmc_traffic.sh); the last committed measurement of this same workload is reported, if present
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+        if args.workload == "gomoku15" and args.evaluator == "fused" and os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath))[dom[0]]
+                traffic = t["FETCH_SIZE"]["corrected_bytes_per_launch"] + t["WRITE_SIZE"]["corrected_bytes_per_launch"]
+                traffic_note = ("bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from separate --pmc passes "
+                                "(scripts/pmc_traffic.sh -> profiles/pmc_traffic_latest.json)")
+            except Exception:
+                traffic = None
         achieved = dom[1] / (dom[2] * 1e-3) / 1e9 if dom[2] > 0 else 0.0
         out = {
             "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
@@ -307,7 +319,8 @@ def main():
             "games_per_sec": total_games / elapsed, "plies_per_sec": slots * world * args.steps / elapsed,
             "mean_plies_per_finished_game": (total_plies / total_games) if total_games else None,
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None, "bytes_per_launch": dom[1], "ms_per_launch": dom[2]},
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": dom[1],
+                         "ms_per_launch": dom[2]},
             "tree_kernels": {"k_select_gather": {"ms": sel_ms, "bytes": sel_bytes, "GBps": sel_bytes / max(sel_ms, 1e-9) / 1e6},
                              "k_expand_backup": {"ms": exp_ms, "bytes": exp_bytes, "GBps": exp_bytes / max(exp_ms, 1e-9) / 1e6},
                              "event_pair_overhead_ms": ev_overhead,
