@@ -35,6 +35,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int CH = 64;          // trunk width
 constexpr int TAP_BYTES = 8192; // one tap of a 64->64 layer: [ks 4][half 2][co 64][8] bf16
+constexpr int HW_BYTES = 784;   // head weights in LDS (3*64+3 floats)
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
   const __bf16 x = (__bf16)a, y = (__bf16)b;
@@ -45,12 +46,20 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 
 __device__ __forceinline__ int act_addr(int p, int chunk) { return p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4); }
 
-template <int N, int BPW>
+// N = board, BPW = boards per workgroup, NPT = 32-cell tiles per wave (4 waves), ST = taps staged per barrier
+template <int N, int BPW, int NPT, int ST_>
 struct Geo {
-  static constexpr int NV = N * N, NVT = BPW * NV;
+  static constexpr int NV = N * N, NVT = BPW * NV, ST = ST_;
   static constexpr int ZERO_OFF = NVT * 128;       // 16 zero bytes
   static constexpr int ACT_BYTES = NVT * 128 + 16;
-  static_assert(NVT <= 256, "8 position tiles of 32");
+  static constexpr int STAGE_BYTES = ST * TAP_BYTES;
+  static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = BPW * 8 * SWB;  // packed input words per group
+  static constexpr int RG_BYTES = ((RGW * 4 + 4 * BPW + 15) / 16) * 16;         // one packed-input staging buffer
+  static_assert(NVT <= 4 * NPT * 32, "4 waves x NPT tiles of 32 cells");
+  static_assert(RGW * 4 <= 64 * 16, "one 16-byte LDS-DMA per lane moves the packed input");
+  static size_t lds_bytes(int n_layers) {
+    return (size_t)ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + (size_t)(1 + n_layers) * CH * 4;
+  }
 };
 
 // async global -> LDS copy of 16 B per lane: the LDS destination is the wave-uniform `lds_base` + lane*16
@@ -59,22 +68,24 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
                                    (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)lds_base, 16, 0, 0);
 }
 
-#ifndef AZ_TOWER_STAGE_TAPS
-#define AZ_TOWER_STAGE_TAPS 3  // taps staged per barrier: 3 = one kernel row (48 KiB of LDS), 1 = one tap (16 KiB)
-#endif
 #ifndef AZ_TOWER_ABLATE
 #define AZ_TOWER_ABLATE 0  // 0 = product; 1 / 2 = timing diagnostics only (wrong results)
+#endif
+// 15x15 geometry: boards per workgroup / cell tiles per wave / taps per stage.  (1,2,3): 2x2 accumulator tiles,
+// one kernel row of weights per barrier.  (2,4,1): 4x2 accumulator tiles (A fragments reused over 4 cell tiles:
+// 25 % fewer LDS fragment reads), one tap per barrier so that two workgroups still fit a CU's LDS.
+#ifndef AZ_TOWER15_BPW
+#define AZ_TOWER15_BPW 1
+#define AZ_TOWER15_NPT 2
+#define AZ_TOWER15_ST 3
 #endif
 #ifndef AZ_TOWER_WAVES_PER_SIMD
 #define AZ_TOWER_WAVES_PER_SIMD 2
 #endif
-constexpr int HW_BYTES = 784, RG_BYTES = 640;  // head weights (3*64+3 floats); one packed-input staging buffer
-constexpr int ST = AZ_TOWER_STAGE_TAPS;
-constexpr int STAGE_BYTES = ST * TAP_BYTES;
 
 // stage ST taps of weights (ST*KS*2 KiB, [tap][ks][half][co][8] bf16) into an LDS buffer:
 // 1 KiB per wave-instruction, chunks dealt round-robin to the 4 waves
-template <int KS>
+template <int KS, int ST>
 __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave, int lane) {
   constexpr int NCHUNK = ST * KS * 2;
 #pragma unroll
@@ -87,29 +98,29 @@ __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave,
 // Weights are staged ST taps at a time, double buffered (9/ST barriers per layer).  On entry stage 0 of THIS
 // layer is already in buffer `buf` (landed and barriered); during the last stage the first stage of the NEXT
 // layer (wnext, KSN k-steps per tap; nullptr = none) is prefetched, so no layer starts with an exposed DMA.
-template <int KS, int KSN, int N, int ZERO_OFF>
+template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST>
 __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext,
-                                           int tid, int lane, const int (&pp)[2], const uint32_t (&vm)[2],
-                                           f32x16 (&acc)[2][2]) {
+                                           int tid, int lane, const int (&pp)[NPT], const uint32_t (&vm)[NPT],
+                                           f32x16 (&acc)[NPT][2]) {
   constexpr int TB = KS * 2048;  // bytes per tap
-  constexpr int NSTAGE = 9 / ST;
+  constexpr int NSTAGE = 9 / ST, STAGE_BYTES = ST * TAP_BYTES;
   const int h = lane >> 5, r = lane & 31, wave = tid >> 6;
 #pragma unroll 1
   for (int sg = 0; sg < NSTAGE; ++sg) {
     // the DMA of the next stage's weights runs under this stage's MFMAs
     char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
-    if (sg < NSTAGE - 1) stage_w<KS>(wg + (sg + 1) * ST * TB, wn, wave, lane);
-    else if (wnext != nullptr) stage_w<KSN>(wnext, wn, wave, lane);
+    if (sg < NSTAGE - 1) stage_w<KS, ST>(wg + (sg + 1) * ST * TB, wn, wave, lane);
+    else if (wnext != nullptr) stage_w<KSN, ST>(wnext, wn, wave, lane);
     const char *wst = wbuf + ((buf + sg) & 1) * STAGE_BYTES;
 #pragma unroll
     for (int j = 0; j < ST; ++j) {
       const int tap = sg * ST + j;
       const char *wc = wst + j * TB;
       const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
-      int q[2], sw[2];
-      bool on[2];
+      int q[NPT], sw[NPT];
+      bool on[NPT];
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
+      for (int pt = 0; pt < NPT; ++pt) {
         q[pt] = (pp[pt] + d) * 128;
         sw[pt] = ((pp[pt] + d) >> 1) & 7;
         on[pt] = (vm[pt] >> tap) & 1u;
@@ -125,7 +136,7 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
         const bf16x8 a1 = *(const bf16x8 *)(wc + chunk * 1024 + 512 + r * 16);
 #endif
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+        for (int pt = 0; pt < NPT; ++pt) {
 #if AZ_TOWER_ABLATE == 2
           bf16x8 b = a0;
           b[0] = (__bf16)(float)(q[pt] + sw[pt]);
@@ -148,12 +159,12 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
 }
 
 // bias (+ residual) + ReLU, bf16, written back in place
-template <bool RES>
-__device__ __forceinline__ void epilogue(char *act, const float *bias, int lane, const int (&pp)[2], const bool (&ok)[2],
-                                         const f32x16 (&acc)[2][2], const uint2 (&res)[2][2][4]) {
+template <bool RES, int NPT>
+__device__ __forceinline__ void epilogue(char *act, const float *bias, int lane, const int (&pp)[NPT], const bool (&ok)[NPT],
+                                         const f32x16 (&acc)[NPT][2], const uint2 (&res)[NPT][2][4]) {
   const int h = lane >> 5;
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
+  for (int pt = 0; pt < NPT; ++pt) {
     if (!ok[pt]) continue;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -172,9 +183,10 @@ __device__ __forceinline__ void epilogue(char *act, const float *bias, int lane,
   }
 }
 
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+template <int NPT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NPT][2]) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NPT; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -191,16 +203,14 @@ __device__ __forceinline__ void glds4(const void *g_lane, void *lds_base) {
 // w0: [9][1][2][64][8] bf16 (first conv, 9 input channels padded to 16).  wl: [L][9][4][2][64][8] bf16.
 // bias: [1+L][64] f32.  headw: [3][64] f32 (policy, value0, value1), headb: [3].
 // pfeat: (G, NV) f32, vfeat: (G, 2, NV) f32 (= the inputs of the heads' Linear layers).
-template <int N, int BPW>
+template <int N, int BPW, int NPT, int ST>
 __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
                                                const int4 *__restrict__ leafrec, int G, const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
                                                float *__restrict__ pfeat, float *__restrict__ vfeat) {
-  using Q = Geo<N, BPW>;
-  constexpr int WC = (Q::NV + 31) / 32, SWB = 2 * WC, RGW = BPW * 8 * SWB;  // packed input words per group
-  constexpr int RG_STRIDE = RG_BYTES;                                       // bytes per input buffer (>= RGW*4 + 4*BPW)
-  static_assert(RGW * 4 + 4 * BPW <= RG_BYTES, "input staging buffer too small");
+  using Q = Geo<N, BPW, NPT, ST>;
+  constexpr int WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RG_STRIDE = Q::RG_BYTES, STAGE_BYTES = Q::STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *act = smem;
   char *wbuf = smem + Q::ACT_BYTES;
@@ -213,13 +223,13 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   for (int i = tid; i < 3 * CH + 3; i += 256) hw[i] = i < 3 * CH ? headw[i] : headb[i - 3 * CH];
   for (int i = tid; i < (1 + L) * CH; i += 256) bl[i] = bias[i];
 
-  // this lane's two cells (B-operand column / accumulator column): tile = 2*wave + pt
-  int pp[2];
-  bool ok[2];
-  uint32_t vm[2];
+  // this lane's NPT cells (B-operand column / accumulator column): tile = NPT*wave + pt
+  int pp[NPT];
+  bool ok[NPT];
+  uint32_t vm[NPT];
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int m = (2 * wave + pt) * 32 + (lane & 31);
+  for (int pt = 0; pt < NPT; ++pt) {
+    const int m = (NPT * wave + pt) * 32 + (lane & 31);
     ok[pt] = m < Q::NVT;
     pp[pt] = ok[pt] ? m : 0;
     const int cell = pp[pt] % Q::NV, row = cell / N, col = cell % N;
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   };
   int buf = 0, inb = 0;
   if (blockIdx.x < ngroups) {  // prologue: the stem's first weight stage and the first group's input
-    stage_w<1>(w0, wbuf, wave, lane);
+    stage_w<1, ST>(w0, wbuf, wave, lane);
     stage_input(blockIdx.x, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -281,36 +291,36 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     inb ^= 1;
     __syncthreads();
 
-    f32x16 acc[2][2];
-    uint2 res[2][2][4];
+    f32x16 acc[NPT][2];
+    uint2 res[NPT][2][4];
     // ---- stem
     zero_acc(acc);
-    if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
-    else conv_layer<1, 1, N, Q::ZERO_OFF>(act, wbuf, buf, w0, has_next ? w0 : nullptr, tid, lane, pp, vm, acc);
-    epilogue<false>(act, bl, lane, pp, ok, acc, res);
+    if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
+    else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, has_next ? w0 : nullptr, tid, lane, pp, vm, acc);
+    epilogue<false, NPT>(act, bl, lane, pp, ok, acc, res);
     __syncthreads();
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
       const int h = lane >> 5;
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
           for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pp[pt], ct * 4 + q) + 8 * h);
       zero_acc(acc);
-      conv_layer<4, 4, N, Q::ZERO_OFF>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
+      conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
                                        lane, pp, vm, acc);
-      epilogue<false>(act, bl + (1 + l) * CH, lane, pp, ok, acc, res);
+      epilogue<false, NPT>(act, bl + (1 + l) * CH, lane, pp, ok, acc, res);
       __syncthreads();
       zero_acc(acc);
       if (l + 2 < L)
-        conv_layer<4, 4, N, Q::ZERO_OFF>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
+        conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
                                          tid, lane, pp, vm, acc);
       else  // last layer of this board: prefetch the next board's stem weights
-        conv_layer<4, 1, N, Q::ZERO_OFF>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, has_next ? w0 : nullptr, tid, lane,
+        conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, has_next ? w0 : nullptr, tid, lane,
                                          pp, vm, acc);
-      epilogue<true>(act, bl + (2 + l) * CH, lane, pp, ok, acc, res);
+      epilogue<true, NPT>(act, bl + (2 + l) * CH, lane, pp, ok, acc, res);
       __syncthreads();
     }
     // ---- heads: 1x1 convs (+folded BN) + ReLU, one position per thread
@@ -356,28 +366,26 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
   if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1)) { g_tower_err = "n_boards >= 1, even n_conv_layers"; return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   hipError_t err;
+  auto launch = [&](auto kern, size_t lds, int bpw) -> int {
+    if (lds > 160 * 1024) { g_tower_err = "too many layers for the LDS bias table"; return AZ_EINVAL; }
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * AZ_TOWER_WAVES_PER_SIMD, grid = groups < cap ? groups : cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
+                       (const int4 *)packed_leaf_dev, n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
+                       n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
+    return AZ_OK;
+  };
+  int rc;
   if (board_size == 15) {
-    constexpr int BPW = 1;
-    const size_t lds = Geo<15, BPW>::ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + (size_t)(1 + n_conv_layers) * CH * 4;
-    if (lds > 160 * 1024) { g_tower_err = "too many layers for the LDS bias table"; return AZ_EINVAL; }
-    (void)hipFuncSetAttribute((const void *)k_tower<15, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 256 * AZ_TOWER_WAVES_PER_SIMD ? groups : 256 * AZ_TOWER_WAVES_PER_SIMD;
-    hipLaunchKernelGGL((k_tower<15, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
-                       (const int4 *)packed_leaf_dev, n_boards, (const char *)w0_dev,
-                       (const char *)wl_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
+    rc = launch(k_tower<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST>,
+                Geo<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST>::lds_bytes(n_conv_layers), AZ_TOWER15_BPW);
   } else if (board_size == 9) {
-    constexpr int BPW = 3;
-    const size_t lds = Geo<9, BPW>::ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + (size_t)(1 + n_conv_layers) * CH * 4;
-    if (lds > 160 * 1024) { g_tower_err = "too many layers for the LDS bias table"; return AZ_EINVAL; }
-    (void)hipFuncSetAttribute((const void *)k_tower<9, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int groups = (n_boards + BPW - 1) / BPW, grid = groups < 256 * AZ_TOWER_WAVES_PER_SIMD ? groups : 256 * AZ_TOWER_WAVES_PER_SIMD;
-    hipLaunchKernelGGL((k_tower<9, BPW>), dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
-                       (const int4 *)packed_leaf_dev, n_boards, (const char *)w0_dev,
-                       (const char *)wl_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
+    rc = launch(k_tower<9, 3, 2, 3>, Geo<9, 3, 2, 3>::lds_bytes(n_conv_layers), 3);
   } else {
     g_tower_err = "board_size must be 9 or 15";
     return AZ_EINVAL;
   }
+  if (rc != AZ_OK) return rc;
   err = hipGetLastError();
   if (err != hipSuccess) { g_tower_err = std::string("k_tower launch: ") + hipGetErrorString(err); return AZ_EHIP; }
   return AZ_OK;

@@ -173,6 +173,7 @@ def main():
     ring = HostSampleRing(max(4 * slots, 65536), (d.nn_channels, d.height, d.width), d.n_action)
     esize = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}[tdtype]
 
+    copy_stream = torch.cuda.Stream(dev)
     games_started = slots
     inv_tao_h = torch.tensor([1.0 / reference_tao(0)] * slots, dtype=torch.float32)
     inv_tao = inv_tao_h.to(dev)
@@ -189,7 +190,12 @@ def main():
         plies, _, _, _ = eng.game_info()
         plies_h = plies.cpu()[idx]
         states, pis, zs, _ = eng.emit_samples(idx.to(torch.int32), plies_h)
-        ring.put_batch(states, pis, zs)
+        # the D2H of the samples runs on a side stream, under the next move's search
+        copy_stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(copy_stream):
+            ring.put_batch(states, pis, zs)
+            for t in (states, pis, zs):
+                t.record_stream(copy_stream)
         finished_games += int(idx.numel())
         finished_plies += int(plies_h.sum())
         for s in idx.tolist():  # per-slot temperature schedule restarts with the new game
