@@ -58,6 +58,8 @@ struct View {  // kernel argument: raw device pointers + sizes
   int32_t *path;
   int4 *leaf;
   uint32_t *leafRing;
+  int32_t *evalCount;  // [1] leaves of this simulation step that need the network ...
+  int32_t *evalList;   // [G] ... and their slots, in arrival order
   uint32_t *traj;
   int8_t *trajPlayer;
   uint16_t *trajVisits;
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
     st[3] += (kind == KIND_EVAL); st[4] += (kind == KIND_TERMINAL);
   }
   if (kind == KIND_EVAL) {
+    if (lane == 0) v.evalList[atomicAdd(v.evalCount, 1)] = g;  // compact list of the slots to evaluate
     uint32_t *lr = v.leafRing + (size_t)g * 8 * GT::SW;
     for (int i = lane; i < 8 * GT::SW; i += 64) lr[i] = hist[(head + i / GT::SW) & 7][i % GT::SW];
     if (nn_input) write_planes<GT, OutT>(hist, head, pl, nn_input + (size_t)g * (GT::CIN * GT::HW), lane);
@@ -725,6 +728,8 @@ int az_create(const az_config *cfg, az_engine **out) {
   v.path = (int32_t *)alloc(G * (size_t)d.depth_cap * sizeof(int32_t));
   v.leaf = (int4 *)alloc(G * sizeof(int4));
   v.leafRing = (uint32_t *)alloc(G * 8 * (size_t)d.state_words * sizeof(uint32_t));
+  v.evalCount = (int32_t *)alloc(64);
+  v.evalList = (int32_t *)alloc(G * sizeof(int32_t));
   v.traj = (uint32_t *)alloc(G * (size_t)(d.max_plies + 1) * d.state_words * sizeof(uint32_t));
   v.trajPlayer = (int8_t *)alloc(G * (size_t)(d.max_plies + 1));
   v.trajVisits = (uint16_t *)alloc(G * (size_t)d.max_plies * A * sizeof(uint16_t));
@@ -743,7 +748,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   d.device_bytes = total;
   // small state starts defined; the big pools need no clearing (bump allocated, written before read)
   if (hipMemset(v.stat, 0, G * 6 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(v.err, 0, sizeof(int32_t)) != hipSuccess || hipMemset(v.active, 0, G) != hipSuccess ||
+      hipMemset(v.err, 0, sizeof(int32_t)) != hipSuccess || hipMemset(v.evalCount, 0, 64) != hipSuccess || hipMemset(v.active, 0, G) != hipSuccess ||
       hipMemset(v.ply, 0, G * sizeof(int32_t)) != hipSuccess || hipMemset(v.leaf, 0, G * sizeof(int4)) != hipSuccess ||
       hipMemset(v.trajPlayer, 0, G * (size_t)(d.max_plies + 1)) != hipSuccess) {
     g_create_err = "hipMemset failed";
@@ -841,10 +846,13 @@ int az_begin_search(az_engine *e, void *stream) {
   return launch_check(e, "k_begin_search");
 }
 
-int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf_dev) {
+int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf_dev, const void **list_dev,
+                    const void **count_dev) {
   if (!e) return AZ_EINVAL;
   if (ring_dev) *ring_dev = e->v.leafRing;
   if (leaf_dev) *leaf_dev = e->v.leaf;
+  if (list_dev) *list_dev = e->v.evalList;
+  if (count_dev) *count_dev = e->v.evalCount;
   return AZ_OK;
 }
 
@@ -852,6 +860,7 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
   if (!e) return AZ_EINVAL;
   const dim3 grid(e->v.G), block(64);
   hipStream_t s = (hipStream_t)stream;
+  AZ_HIP(hipMemsetAsync(e->v.evalCount, 0, sizeof(int32_t), s));
   switch (e->cfg.nn_dtype) {
     case AZ_NN_F32: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, float>), grid, block, 0, s, e->v, (float *)nn_input_dev)); break;
     case AZ_NN_BF16: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, bf16_t>), grid, block, 0, s, e->v, (bf16_t *)nn_input_dev)); break;

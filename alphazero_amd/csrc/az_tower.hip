@@ -54,7 +54,7 @@ struct Geo {
   static constexpr int ACT_BYTES = NVT * 128 + 16;
   static constexpr int STAGE_BYTES = ST * TAP_BYTES;
   static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = BPW * 8 * SWB;  // packed input words per group
-  static constexpr int RG_BYTES = ((RGW * 4 + 4 * BPW + 15) / 16) * 16;         // one packed-input staging buffer
+  static constexpr int RG_BYTES = ((RGW * 4 + 8 * BPW + 15) / 16) * 16;         // ring words, BPW players, BPW slots
   static_assert(NVT <= 4 * NPT * 32, "4 waves x NPT tiles of 32 cells");
   static_assert(RGW * 4 <= 64 * 16, "one 16-byte LDS-DMA per lane moves the packed input");
   static size_t lds_bytes(int n_layers) {
@@ -78,6 +78,9 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 #define AZ_TOWER15_BPW 1
 #define AZ_TOWER15_NPT 2
 #define AZ_TOWER15_ST 3
+#endif
+#ifndef AZ_TOWER9_ST
+#define AZ_TOWER9_ST 1  // 9x9 (3 boards per workgroup): per-tap staging keeps two workgroups within a CU's 160 KiB of LDS
 #endif
 #ifndef AZ_TOWER_WAVES_PER_SIMD
 #define AZ_TOWER_WAVES_PER_SIMD 2
@@ -205,7 +208,8 @@ __device__ __forceinline__ void glds4(const void *g_lane, void *lds_base) {
 // pfeat: (G, NV) f32, vfeat: (G, 2, NV) f32 (= the inputs of the heads' Linear layers).
 template <int N, int BPW, int NPT, int ST>
 __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
-                                               const int4 *__restrict__ leafrec, int G, const char *__restrict__ w0,
+                                               const int4 *__restrict__ leafrec, const int32_t *__restrict__ list,
+                                               const int32_t *__restrict__ count, int G, const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
                                                float *__restrict__ pfeat, float *__restrict__ vfeat) {
@@ -242,33 +246,54 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     vm[pt] = ok[pt] ? mask : 0u;
   }
 
-  const int ngroups = (G + BPW - 1) / BPW;
-  // DMA of one group's packed input (ring words + players) into input buffer `which` (wave 0 only)
-  auto stage_input = [&](int grp, int which) {
-    if (wave != 0 || x != nullptr) return;
-    const int nb = min(BPW, G - grp * BPW);
+  // boards to evaluate: the engine's compact list (packed mode) or all G rows
+  const int nb_total = (list != nullptr && count != nullptr) ? min(*count, G) : G;
+  const int ngroups = (nb_total + BPW - 1) / BPW;
+  constexpr int BOARD_BYTES = 8 * SWB * 4;
+  // wave 0, lane k keeps the slots of this workgroup's k-th group (<= 64 groups per workgroup, see the host side)
+  int sl[BPW];
+#pragma unroll
+  for (int b = 0; b < BPW; ++b) {
+    const int ci = (blockIdx.x + lane * (int)gridDim.x) * BPW + b;
+    sl[b] = (wave == 0 && ci < nb_total) ? (list != nullptr ? list[ci] : ci) : -1;
+  }
+  // stage the `it`-th group's input into buffer `which` (wave 0): slots by ds_write, ring words + players by LDS-DMA
+  auto stage_input = [&](int it, int which) {
+    if (wave != 0) return;
     char *dst = rgb + which * RG_STRIDE;
-    if (lane * 16 < nb * 8 * SWB * 4) glds16((const char *)(ring + (size_t)grp * RGW) + lane * 16, dst);
-    if (lane < nb) glds4(&leafrec[grp * BPW + lane].w, dst + RGW * 4);
+    int mine = -1, dma_slot = -1;
+    const int db = (lane * 16) / BOARD_BYTES;  // the board this lane's 16-byte DMA piece belongs to
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) {
+      const int sb = __shfl(sl[b], it, 64);
+      if (lane == b) mine = sb;
+      if (db == b) dma_slot = sb;
+    }
+    if (lane < BPW) ((int *)dst)[RGW + BPW + lane] = mine;
+    if (x != nullptr) return;
+    if (lane * 16 < BPW * BOARD_BYTES && dma_slot >= 0)
+      glds16((const char *)ring + (size_t)dma_slot * BOARD_BYTES + (lane * 16) % BOARD_BYTES, dst);
+    if (lane < BPW && mine >= 0) glds4(&leafrec[mine].w, dst + RGW * 4);
   };
-  int buf = 0, inb = 0;
+  int buf = 0, inb = 0, it = 0;
   if (blockIdx.x < ngroups) {  // prologue: the stem's first weight stage and the first group's input
     stage_w<1, ST>(w0, wbuf, wave, lane);
-    stage_input(blockIdx.x, 0);
+    stage_input(0, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x, ++it) {
     const bool has_next = grp + (int)gridDim.x < ngroups;
-    if (has_next) stage_input(grp + gridDim.x, inb ^ 1);  // lands under this group's tower
+    if (has_next) stage_input(it + 1, inb ^ 1);  // lands under this group's tower
     // ---- input -> act[cell][0..15] (channels 9..15 zero): the NCHW bf16 planes, or the packed leaf batch
     // (8 bitboard states per board + the player to move), expanded here
     const uint32_t *rg = (const uint32_t *)(rgb + inb * RG_STRIDE);
+    const int *slots = (const int *)rg + RGW + BPW;
     for (int m = tid; m < Q::NVT; m += 256) {
-      const int b = m / Q::NV, cell = m % Q::NV, g = grp * BPW + b;
+      const int b = m / Q::NV, cell = m % Q::NV, g = slots[b];
       uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (g < G) {
+      if (g >= 0) {
         if (x != nullptr) {
           const uint16_t *xr = x + (size_t)g * 9 * Q::NV + cell;
 #pragma unroll
@@ -325,8 +350,8 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     }
     // ---- heads: 1x1 convs (+folded BN) + ReLU, one position per thread
     for (int m = tid; m < Q::NVT; m += 256) {
-      const int b = m / Q::NV, cell = m % Q::NV, g = grp * BPW + b;
-      if (g >= G) continue;
+      const int b = m / Q::NV, cell = m % Q::NV, g = slots[b];
+      if (g < 0) continue;
       float s0 = hw[3 * CH + 0], s1 = hw[3 * CH + 1], s2 = hw[3 * CH + 2];
 #pragma unroll
       for (int chunk = 0; chunk < 8; ++chunk) {
@@ -358,7 +383,8 @@ extern "C" {
 const char *az_tower_last_error(void) { return g_tower_err.c_str(); }
 
 int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
-                     const void *packed_ring_dev, const void *packed_leaf_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
+                     const void *packed_ring_dev, const void *packed_leaf_dev, const void *list_dev,
+                     const void *count_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
                      const float *headb_dev, float *pfeat_dev, float *vfeat_dev, void *stream) {
   using namespace aztower;
   if ((!x_bf16_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !pfeat_dev || !vfeat_dev ||
@@ -369,9 +395,13 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
   auto launch = [&](auto kern, size_t lds, int bpw) -> int {
     if (lds > 160 * 1024) { g_tower_err = "too many layers for the LDS bias table"; return AZ_EINVAL; }
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * AZ_TOWER_WAVES_PER_SIMD, grid = groups < cap ? groups : cap;
+    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * AZ_TOWER_WAVES_PER_SIMD;
+    int grid = groups < cap ? groups : cap;
+    if ((groups + grid - 1) / grid > 64) grid = (groups + 63) / 64;  // a workgroup keeps <= 64 groups' slots in one wave
+    const bool use_list = !x_bf16_dev && list_dev && count_dev;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
-                       (const int4 *)packed_leaf_dev, n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
+                       (const int4 *)packed_leaf_dev, (const int32_t *)(use_list ? list_dev : nullptr),
+                       (const int32_t *)(use_list ? count_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
                        n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
     return AZ_OK;
   };
@@ -380,7 +410,7 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
     rc = launch(k_tower<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST>,
                 Geo<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST>::lds_bytes(n_conv_layers), AZ_TOWER15_BPW);
   } else if (board_size == 9) {
-    rc = launch(k_tower<9, 3, 2, 3>, Geo<9, 3, 2, 3>::lds_bytes(n_conv_layers), 3);
+    rc = launch(k_tower<9, 3, 2, AZ_TOWER9_ST>, Geo<9, 3, 2, AZ_TOWER9_ST>::lds_bytes(n_conv_layers), 3);
   } else {
     g_tower_err = "board_size must be 9 or 15";
     return AZ_EINVAL;

@@ -77,8 +77,8 @@ def load_library() -> C.CDLL:
     lib.az_reset_stats.argtypes = [vp, vp]
     lib.az_eval_hash.argtypes = [vp, vp, C.c_float, vp, vp, vp]
     lib.az_augment_samples.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
-    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.az_leaf_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.az_leaf_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
     for name in EXPORTS:
@@ -201,10 +201,11 @@ class Engine:
         self._ck(self.lib.az_begin_search(self._h, self._stream()))
 
     def leaf_buffers(self):
-        """device addresses (ints) of the packed leaf batch: (ring u32 (G,8,SW), leaf records int32 (G,4))"""
-        ring, leaf = C.c_void_p(), C.c_void_p()
-        self._ck(self.lib.az_leaf_buffers(self._h, C.byref(ring), C.byref(leaf)))
-        return ring.value, leaf.value
+        """device addresses (ints) of the packed leaf batch: (ring u32 (G,8,SW), leaf records int32 (G,4),
+        list of slots to evaluate i32 (G), their count i32)"""
+        ring, leaf, lst, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.az_leaf_buffers(self._h, C.byref(ring), C.byref(leaf), C.byref(lst), C.byref(cnt)))
+        return ring.value, leaf.value, lst.value, cnt.value
 
     def select_gather(self, nn_input=None):
         """nn_input None: only the packed leaf batch is produced (what the fused tower reads)"""

@@ -89,24 +89,27 @@ class FusedTowerEvaluator:
         self.v2_wt, self.v2_b = f(v2.weight).t().contiguous(), f(v2.bias)
 
     def __call__(self, x: torch.Tensor | None, logits_out: torch.Tensor | None = None, packed=None, n_boards: int = 0):
-        """x: contiguous (B,9,N,N) bf16 batch, or None with packed=(ring_ptr, leaf_ptr) from Engine.leaf_buffers()
-        and n_boards = the engine's slot count (the packed leaf batch is read straight from the engine)."""
+        """x: contiguous (B,9,N,N) bf16 batch, or None with packed = Engine.leaf_buffers() (ring, leaf[, list, count])
+        and n_boards = the engine's slot count: the packed leaf batch is read straight from the engine and, when the
+        list is given, only the slots whose leaf needs the network are evaluated (other output rows keep old data)."""
         if x is not None:
             if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
                 raise EngineError("FusedTowerEvaluator expects a contiguous (B,9,N,N) bf16 batch on the model's GPU")
             B = x.shape[0]
-            ring_p = leaf_p = None
+            ring_p = leaf_p = list_p = count_p = None
         else:
             if packed is None or n_boards < 1:
                 raise EngineError("FusedTowerEvaluator: give either x or packed=(ring, leaf) with n_boards")
             B = n_boards
             ring_p, leaf_p = C.c_void_p(packed[0]), C.c_void_p(packed[1])
+            list_p = C.c_void_p(packed[2]) if len(packed) > 3 and packed[2] else None
+            count_p = C.c_void_p(packed[3]) if len(packed) > 3 and packed[3] else None
         if B not in self._buf:
-            self._buf[B] = (torch.empty(B, self.n2, device=self.device), torch.empty(B, 2 * self.n2, device=self.device))
+            self._buf[B] = (torch.zeros(B, self.n2, device=self.device), torch.zeros(B, 2 * self.n2, device=self.device))
         pfeat, vfeat = self._buf[B]
         P = lambda t: C.c_void_p(t.data_ptr())
         rc = self.lib.az_tower_forward(self.board, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
-                                       P(self.w0), P(self.wl), P(self.bias),
+                                       list_p, count_p, P(self.w0), P(self.wl), P(self.bias),
                                        P(self.headw), P(self.headb), P(pfeat), P(vfeat),
                                        C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:

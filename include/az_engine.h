@@ -107,9 +107,12 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream);
 
 /* The packed leaf batch of the last az_select_gather, engine-owned, read-only for the caller:
  * ring_dev -> u32 (n_slots, 8, state_words): each leaf's 8-state history as bitboards, oldest first;
- * leaf_dev -> int32 x4 per slot {depth, kind (0 = needs the network, 1 = terminal), value bits, player}.
- * Consumed by az_tower_forward; ~8x fewer bytes than the dense planes. */
-int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf_dev);
+ * leaf_dev -> int32 x4 per slot {depth, kind (0 = needs the network, 1 = terminal), value bits, player};
+ * list_dev -> i32 (n_slots): the slots whose leaf needs the network, in no particular order;
+ * count_dev -> i32: how many (terminal leaves, re-visited every time the reference revisits them, are absent).
+ * Consumed by az_tower_forward; ~8x fewer bytes than the dense planes.  Any out pointer may be NULL. */
+int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf_dev, const void **list_dev,
+                    const void **count_dev);
 
 /* The rest of that simulation: _get_prior :180-192 (softmax, Dirichlet mix at the root, legal mask,
  * renormalise), MCTSNode.expand :43-57, value.item() :170 and _bacaward :194-200.
@@ -179,13 +182,15 @@ int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *log
  * with eval-mode BatchNorm folded in by the host and ReLU fused, activations resident in LDS.
  *   x_bf16_dev (n_boards, 9, N, N) bf16 = the batch az_select_gather writes with AZ_NN_BF16, or NULL to read
  *   the packed leaf batch instead (packed_ring_dev / packed_leaf_dev from az_leaf_buffers of a gomoku engine
- *   of the same board size; both may be NULL when x_bf16_dev is given);
+ *   of the same board size; both may be NULL when x_bf16_dev is given); with list_dev / count_dev (same call,
+ *   or NULL) only the listed slots are evaluated and only their rows of pfeat / vfeat are written;
  *   w0_dev [9][1][2][64][8] bf16, wl_dev [n_conv_layers][9][4][2][64][8] bf16 ([tap][k-step][k-half][co][8 ci]);
  *   bias_dev [1+n_conv_layers][64] f32; headw_dev [3][64] f32, headb_dev [3] f32 (policy, value0, value1);
  *   pfeat_dev (n_boards, N*N) f32 and vfeat_dev (n_boards, 2, N*N) f32 out: the inputs of the heads'
  *   Linear layers (which stay in PyTorch).  board_size N in {9, 15}. */
 int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
-                     const void *packed_ring_dev, const void *packed_leaf_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
+                     const void *packed_ring_dev, const void *packed_leaf_dev, const void *list_dev,
+                     const void *count_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
                      const float *headb_dev, float *pfeat_dev, float *vfeat_dev, void *stream);
 const char *az_tower_last_error(void);
 

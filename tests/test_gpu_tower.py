@@ -85,9 +85,19 @@ def test_packed_leaf_batch_equals_dense_planes(board):
         eng.select_gather(nn)
         eng.eval_hash(nn, logits, values, 6.0)
         eng.expand_backup(logits, values, None)
+    before = eng.read_stats()
     eng.select_gather(nn)
+    n_eval = eng.read_stats()["evals"] - before["evals"]
     p1, v1 = ev(nn)
     p1, v1 = p1.clone(), v1.clone()
-    p2, v2 = ev(None, packed=eng.leaf_buffers(), n_boards=G)
+    ring, leaf, lst, cnt = eng.leaf_buffers()
+    p2, v2 = ev(None, packed=(ring, leaf), n_boards=G)          # packed, every slot
     eng.check()
     assert torch.equal(p1, p2) and torch.equal(v1, v2)
+    for t in ev._buf[G]:
+        t.zero_()
+    p3, v3 = ev(None, packed=(ring, leaf, lst, cnt), n_boards=G)  # packed + compact list: only leaves that need the net
+    pfeat = ev._buf[G][0]
+    touched = pfeat.abs().sum(1) > 0
+    assert 0 < n_eval <= G and int(touched.sum()) == n_eval
+    assert torch.equal(p3[touched], p1[touched]) and torch.equal(v3[touched], v1[touched])
