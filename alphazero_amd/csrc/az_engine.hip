@@ -251,11 +251,32 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
     st[3] += (kind == KIND_EVAL); st[4] += (kind == KIND_TERMINAL);
   }
   if (kind == KIND_EVAL) {
-    if (lane == 0) v.evalList[atomicAdd(v.evalCount, 1)] = g;  // compact list of the slots to evaluate
     uint32_t *lr = v.leafRing + (size_t)g * 8 * GT::SW;
     for (int i = lane; i < 8 * GT::SW; i += 64) lr[i] = hist[(head + i / GT::SW) & 7][i % GT::SW];
     if (nn_input) write_planes<GT, OutT>(hist, head, pl, nn_input + (size_t)g * (GT::CIN * GT::HW), lane);
   }
+}
+
+// Compact list of the slots whose leaf needs the network (kind == EVAL), in slot order: one workgroup, each
+// thread owns a contiguous run of slots, block-wide exclusive scan of the per-thread counts in LDS.  (A single
+// atomic counter bumped by 16,384 waves costs ~190 us: one word takes ~88 returning atomics per us.)
+__global__ __launch_bounds__(1024) void k_compact_leaves(View v) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (v.G + 1023) / 1024, lo = t * per, hi = min(v.G, lo + per);
+  int n = 0;
+  for (int g = lo; g < hi; ++g) n += (v.active[g] && v.leaf[g].y == KIND_EVAL);
+  part[t] = n;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const int add = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  int pos = part[t] - n;
+  for (int g = lo; g < hi; ++g)
+    if (v.active[g] && v.leaf[g].y == KIND_EVAL) v.evalList[pos++] = g;
+  if (t == 1023) v.evalCount[0] = part[1023];
 }
 
 // ------------------------------------------------------------------------- expand + backup ----
@@ -860,13 +881,14 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
   if (!e) return AZ_EINVAL;
   const dim3 grid(e->v.G), block(64);
   hipStream_t s = (hipStream_t)stream;
-  AZ_HIP(hipMemsetAsync(e->v.evalCount, 0, sizeof(int32_t), s));
   switch (e->cfg.nn_dtype) {
     case AZ_NN_F32: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, float>), grid, block, 0, s, e->v, (float *)nn_input_dev)); break;
     case AZ_NN_BF16: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, bf16_t>), grid, block, 0, s, e->v, (bf16_t *)nn_input_dev)); break;
     default: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, f16_t>), grid, block, 0, s, e->v, (f16_t *)nn_input_dev)); break;
   }
-  return launch_check(e, "k_select_gather");
+  if (launch_check(e, "k_select_gather") != AZ_OK) return AZ_EHIP;
+  hipLaunchKernelGGL(k_compact_leaves, dim3(1), dim3(1024), 0, s, e->v);
+  return launch_check(e, "k_compact_leaves");
 }
 
 int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev, void *stream) {
