@@ -59,7 +59,8 @@ struct View {  // kernel argument: raw device pointers + sizes
   int4 *leaf;
   uint32_t *leafRing;
   int32_t *evalCount;  // [1] leaves of this simulation step that need the network ...
-  int32_t *evalList;   // [G] ... and their slots, in arrival order
+  int32_t *evalList;   // [G] ... and their slots, in slot order
+  uint8_t *evalFlag;   // [G padded to 16 K] 1 where the slot's leaf needs the network
   uint32_t *traj;
   int8_t *trajPlayer;
   uint16_t *trajVisits;
@@ -182,7 +183,7 @@ __device__ __forceinline__ void load_ring(const uint32_t *tb, int ply, uint32_t 
 template <class GT, typename OutT>
 __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
   const int g = blockIdx.x, lane = threadIdx.x;
-  if (!v.active[g]) return;
+  if (!v.active[g]) { if (lane == 0) v.evalFlag[g] = 0; return; }
   __shared__ uint32_t hist[8][GT::SW];
   __shared__ uint32_t cur[GT::SW];
   const int ply = v.ply[g];
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
   }
   if (lane == 0) {
     v.leaf[g] = make_int4(depth, kind, (int)__float_as_uint(tval), pl);
+    v.evalFlag[g] = kind == KIND_EVAL;
     unsigned long long *st = v.stat + (size_t)g * 6;
     st[0] += 1; st[1] += (unsigned)depth; st[2] += scanned;
     st[3] += (kind == KIND_EVAL); st[4] += (kind == KIND_TERMINAL);
@@ -257,14 +259,19 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
   }
 }
 
-// Compact list of the slots whose leaf needs the network (kind == EVAL), in slot order: one workgroup, each
-// thread owns a contiguous run of slots, block-wide exclusive scan of the per-thread counts in LDS.  (A single
-// atomic counter bumped by 16,384 waves costs ~190 us: one word takes ~88 returning atomics per us.)
-__global__ __launch_bounds__(1024) void k_compact_leaves(View v) {
+// Compact list of the slots whose leaf needs the network, in slot order: one workgroup; each thread owns a
+// contiguous run of `per` slots (a multiple of 16) whose byte flags it reads 16 at a time, then a block-wide scan
+// of the per-thread counts in LDS.  (A single atomic counter bumped by 16,384 waves costs ~190 us: one word takes
+// ~88 returning atomics per us.)
+__global__ __launch_bounds__(1024) void k_compact_leaves(View v, int per) {
   __shared__ int part[1024];
-  const int t = threadIdx.x, per = (v.G + 1023) / 1024, lo = t * per, hi = min(v.G, lo + per);
+  const int t = threadIdx.x, lo = t * per;
+  const uint4 *fl = (const uint4 *)(v.evalFlag + lo);
   int n = 0;
-  for (int g = lo; g < hi; ++g) n += (v.active[g] && v.leaf[g].y == KIND_EVAL);
+  for (int c = 0; c < per / 16; ++c) {
+    const uint4 f = fl[c];
+    n += __popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w);  // flags are 0 / 1 bytes
+  }
   part[t] = n;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -274,8 +281,14 @@ __global__ __launch_bounds__(1024) void k_compact_leaves(View v) {
     __syncthreads();
   }
   int pos = part[t] - n;
-  for (int g = lo; g < hi; ++g)
-    if (v.active[g] && v.leaf[g].y == KIND_EVAL) v.evalList[pos++] = g;
+  if (n > 0)
+    for (int c = 0; c < per / 16; ++c) {
+      const uint4 f = fl[c];
+      const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if ((w[k >> 2] >> (8 * (k & 3))) & 1u) v.evalList[pos++] = lo + c * 16 + k;
+    }
   if (t == 1023) v.evalCount[0] = part[1023];
 }
 
@@ -751,6 +764,8 @@ int az_create(const az_config *cfg, az_engine **out) {
   v.leafRing = (uint32_t *)alloc(G * 8 * (size_t)d.state_words * sizeof(uint32_t));
   v.evalCount = (int32_t *)alloc(64);
   v.evalList = (int32_t *)alloc(G * sizeof(int32_t));
+  const size_t flag_bytes = (size_t)((d.n_slots + 16383) / 16384) * 16384;  // 1024 threads x a multiple of 16 flags
+  v.evalFlag = (uint8_t *)alloc(flag_bytes);
   v.traj = (uint32_t *)alloc(G * (size_t)(d.max_plies + 1) * d.state_words * sizeof(uint32_t));
   v.trajPlayer = (int8_t *)alloc(G * (size_t)(d.max_plies + 1));
   v.trajVisits = (uint16_t *)alloc(G * (size_t)d.max_plies * A * sizeof(uint16_t));
@@ -769,7 +784,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   d.device_bytes = total;
   // small state starts defined; the big pools need no clearing (bump allocated, written before read)
   if (hipMemset(v.stat, 0, G * 6 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(v.err, 0, sizeof(int32_t)) != hipSuccess || hipMemset(v.evalCount, 0, 64) != hipSuccess || hipMemset(v.active, 0, G) != hipSuccess ||
+      hipMemset(v.err, 0, sizeof(int32_t)) != hipSuccess || hipMemset(v.evalCount, 0, 64) != hipSuccess || hipMemset(v.evalFlag, 0, flag_bytes) != hipSuccess || hipMemset(v.active, 0, G) != hipSuccess ||
       hipMemset(v.ply, 0, G * sizeof(int32_t)) != hipSuccess || hipMemset(v.leaf, 0, G * sizeof(int4)) != hipSuccess ||
       hipMemset(v.trajPlayer, 0, G * (size_t)(d.max_plies + 1)) != hipSuccess) {
     g_create_err = "hipMemset failed";
@@ -887,7 +902,7 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
     default: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, f16_t>), grid, block, 0, s, e->v, (f16_t *)nn_input_dev)); break;
   }
   if (launch_check(e, "k_select_gather") != AZ_OK) return AZ_EHIP;
-  hipLaunchKernelGGL(k_compact_leaves, dim3(1), dim3(1024), 0, s, e->v);
+  hipLaunchKernelGGL(k_compact_leaves, dim3(1), dim3(1024), 0, s, e->v, ((e->v.G + 16383) / 16384) * 16);
   return launch_check(e, "k_compact_leaves");
 }
 
