@@ -92,6 +92,7 @@ class SelfPlayRunner:
     # one model forward on the gathered batch -> self.logits / self.values (f32, engine device)
     def evaluate(self) -> None:
         if self.fused is not None:
+            self.e.compact_leaves()  # terminal leaves cost no network evaluation
             _, v = self.fused(None, logits_out=self.logits, packed=self._packed, n_boards=self.e.n_slots)
             self.values = v.view(-1)  # handed to expand_backup as is (no copy)
             return

@@ -901,8 +901,12 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
     case AZ_NN_BF16: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, bf16_t>), grid, block, 0, s, e->v, (bf16_t *)nn_input_dev)); break;
     default: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, f16_t>), grid, block, 0, s, e->v, (f16_t *)nn_input_dev)); break;
   }
-  if (launch_check(e, "k_select_gather") != AZ_OK) return AZ_EHIP;
-  hipLaunchKernelGGL(k_compact_leaves, dim3(1), dim3(1024), 0, s, e->v, ((e->v.G + 16383) / 16384) * 16);
+  return launch_check(e, "k_select_gather");
+}
+
+int az_compact_leaves(az_engine *e, void *stream) {
+  if (!e) return AZ_EINVAL;
+  hipLaunchKernelGGL(k_compact_leaves, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->v, ((e->v.G + 16383) / 16384) * 16);
   return launch_check(e, "k_compact_leaves");
 }
 

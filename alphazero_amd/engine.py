@@ -40,7 +40,7 @@ class AzStats(C.Structure):
 EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check", "az_reset_games",
            "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_root_policy",
            "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
-           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_augment_samples", "az_leaf_buffers"]
+           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_augment_samples", "az_leaf_buffers", "az_compact_leaves"]
 
 _lib = None
 
@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     lib.az_eval_hash.argtypes = [vp, vp, C.c_float, vp, vp, vp]
     lib.az_augment_samples.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
     lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.az_compact_leaves.argtypes = [vp, vp]
     lib.az_leaf_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
@@ -206,6 +207,10 @@ class Engine:
         ring, leaf, lst, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         self._ck(self.lib.az_leaf_buffers(self._h, C.byref(ring), C.byref(leaf), C.byref(lst), C.byref(cnt)))
         return ring.value, leaf.value, lst.value, cnt.value
+
+    def compact_leaves(self):
+        """fill the list/count of leaf_buffers() for the batch of the last select_gather"""
+        self._ck(self.lib.az_compact_leaves(self._h, self._stream()))
 
     def select_gather(self, nn_input=None):
         """nn_input None: only the packed leaf batch is produced (what the fused tower reads)"""

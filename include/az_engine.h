@@ -108,11 +108,13 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream);
 /* The packed leaf batch of the last az_select_gather, engine-owned, read-only for the caller:
  * ring_dev -> u32 (n_slots, 8, state_words): each leaf's 8-state history as bitboards, oldest first;
  * leaf_dev -> int32 x4 per slot {depth, kind (0 = needs the network, 1 = terminal), value bits, player};
- * list_dev -> i32 (n_slots): the slots whose leaf needs the network, in no particular order;
- * count_dev -> i32: how many (terminal leaves, re-visited every time the reference revisits them, are absent).
+ * list_dev -> i32 (n_slots): the slots whose leaf needs the network, ascending, and count_dev -> i32: how many
+ * (terminal leaves, which the reference re-evaluates by rule on every revisit, are absent); both are filled by
+ * az_compact_leaves, to be called after az_select_gather when they are wanted.
  * Consumed by az_tower_forward; ~8x fewer bytes than the dense planes.  Any out pointer may be NULL. */
 int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf_dev, const void **list_dev,
                     const void **count_dev);
+int az_compact_leaves(az_engine *e, void *stream);
 
 /* The rest of that simulation: _get_prior :180-192 (softmax, Dirichlet mix at the root, legal mask,
  * renormalise), MCTSNode.expand :43-57, value.item() :170 and _bacaward :194-200.

@@ -90,6 +90,7 @@ def test_packed_leaf_batch_equals_dense_planes(board):
     n_eval = eng.read_stats()["evals"] - before["evals"]
     p1, v1 = ev(nn)
     p1, v1 = p1.clone(), v1.clone()
+    eng.compact_leaves()
     ring, leaf, lst, cnt = eng.leaf_buffers()
     p2, v2 = ev(None, packed=(ring, leaf), n_boards=G)          # packed, every slot
     eng.check()
