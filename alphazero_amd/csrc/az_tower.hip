@@ -44,18 +44,24 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
+// An empty asm the compiler must assume rewrites v: address arithmetic derived from the result cannot be hoisted out
+// of the persistent loop and parked in registers across the conv layers (that cost ~100 VGPRs and serialised the
+// fragment reads of the inner loop).
+__device__ __forceinline__ int fresh(int v) { asm volatile("" : "+v"(v)); return v; }
+
 __device__ __forceinline__ int act_addr(int p, int chunk) { return p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4); }
 
 // N = board, BPW = boards per workgroup, NPT = 32-cell tiles per wave (4 waves), ST = taps staged per barrier
 template <int N, int BPW, int NPT, int ST_>
 struct Geo {
   static constexpr int NV = N * N, NVT = BPW * NV, ST = ST_;
-  static constexpr int ZERO_OFF = NVT * 128;       // 16 zero bytes
-  static constexpr int ACT_BYTES = NVT * 128 + 16;
+  static constexpr int ZERO_OFF = NVT * 128;       // one all-zero 128-byte row: where taps off the board read
+  static constexpr int ACT_BYTES = NVT * 128 + 128;
   static constexpr int STAGE_BYTES = ST * TAP_BYTES;
   static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = BPW * 8 * SWB;  // packed input words per group
   static constexpr int RG_BYTES = ((RGW * 4 + 8 * BPW + 15) / 16) * 16;         // ring words, BPW players, BPW slots
   static_assert(NVT <= 4 * NPT * 32, "4 waves x NPT tiles of 32 cells");
+  static_assert(NPT == 2 || NPT == 4, "conv_layer counts its fragment reads for 2 or 4 cell tiles per wave");
   static_assert(RGW * 4 <= 64 * 16, "one 16-byte LDS-DMA per lane moves the packed input");
   static size_t lds_bytes(int n_layers) {
     return (size_t)ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + (size_t)(1 + n_layers) * CH * 4;
@@ -91,6 +97,9 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 template <int KS, int ST>
 __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave, int lane) {
   constexpr int NCHUNK = ST * KS * 2;
+#if AZ_TOWER_ABLATE == 3  // diagnostic build: no weight streaming at all
+  return;
+#endif
 #pragma unroll
   for (int c = 0; c < NCHUNK; c += 4)
     if (c + wave < NCHUNK) glds16(wg_src + (c + wave) * 1024 + lane * 16, dst + (c + wave) * 1024);
@@ -101,59 +110,73 @@ __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave,
 // Weights are staged ST taps at a time, double buffered (9/ST barriers per layer).  On entry stage 0 of THIS
 // layer is already in buffer `buf` (landed and barriered); during the last stage the first stage of the NEXT
 // layer (wnext, KSN k-steps per tap; nullptr = none) is prefetched, so no layer starts with an exposed DMA.
+// The k-steps of a stage are software pipelined through two register sets: the four fragment reads of step
+// i+1 are issued before the four MFMAs of step i.  A lane's B address for a tap is ONE base (the 128-byte row of
+// the shifted cell with the swizzle of its first chunk folded in, or the 128-byte zero row when the tap is off
+// the board); the k-step then only XORs (ks << 5) into it.
 template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST>
 __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext,
                                            int tid, int lane, const int (&pp)[NPT], const uint32_t (&vm)[NPT],
                                            f32x16 (&acc)[NPT][2]) {
   constexpr int TB = KS * 2048;  // bytes per tap
-  constexpr int NSTAGE = 9 / ST, STAGE_BYTES = ST * TAP_BYTES;
-  const int h = lane >> 5, r = lane & 31, wave = tid >> 6;
+  constexpr int NSTAGE = 9 / ST, STAGE_BYTES = ST * TAP_BYTES, NK = ST * KS;
+  const int h = lane >> 5, r = lane & 31, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll 1
   for (int sg = 0; sg < NSTAGE; ++sg) {
     // the DMA of the next stage's weights runs under this stage's MFMAs
     char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
     if (sg < NSTAGE - 1) stage_w<KS, ST>(wg + (sg + 1) * ST * TB, wn, wave, lane);
     else if (wnext != nullptr) stage_w<KSN, ST>(wnext, wn, wave, lane);
-    const char *wst = wbuf + ((buf + sg) & 1) * STAGE_BYTES;
+    const char *wa = wbuf + ((buf + sg) & 1) * STAGE_BYTES + h * 1024 + r * 16;
+    uint32_t bb[ST][NPT];
 #pragma unroll
     for (int j = 0; j < ST; ++j) {
       const int tap = sg * ST + j;
-      const char *wc = wst + j * TB;
       const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
-      int q[NPT], sw[NPT];
-      bool on[NPT];
 #pragma unroll
       for (int pt = 0; pt < NPT; ++pt) {
-        q[pt] = (pp[pt] + d) * 128;
-        sw[pt] = ((pp[pt] + d) >> 1) & 7;
-        on[pt] = (vm[pt] >> tap) & 1u;
+        const uint32_t q = (uint32_t)(pp[pt] + d);
+        const uint32_t in = (q << 7) | ((((q >> 1) & 7u) ^ (uint32_t)h) << 4);
+        bb[j][pt] = ((vm[pt] >> tap) & 1u) ? in : (uint32_t)(ZERO_OFF | (h << 4));
       }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int chunk = ks * 2 + h;
+    }
+    // Fragment reads are inline asm with hand-counted waits: hipcc's own ds_read + MFMA schedule here reads each
+    // fragment just before its MFMA and waits lgkmcnt(0) every time (one exposed LDS round trip per two MFMAs).
+    bf16x8 fa[2][2], fb[2][NPT];
+    const uint32_t wa32 = (uint32_t)(uintptr_t)wa, act32 = (uint32_t)(uintptr_t)act;
+    auto load = [&](int i, int s) {
+      const int j = i / KS, ks = i % KS;
 #if AZ_TOWER_ABLATE == 2  // diagnostic build: MFMAs on register operands, no LDS fragment reads
-        bf16x8 a0, a1;
-        for (int z = 0; z < 8; ++z) { a0[z] = (__bf16)(float)(chunk + z); a1[z] = (__bf16)(float)(r + z); }
-#else
-        const bf16x8 a0 = *(const bf16x8 *)(wc + chunk * 1024 + r * 16);
-        const bf16x8 a1 = *(const bf16x8 *)(wc + chunk * 1024 + 512 + r * 16);
+      if (i < 2) { fa[s][0] = fa[s][1] = (bf16x8)(__bf16)1.0f; for (int pt = 0; pt < NPT; ++pt) fb[s][pt] = (bf16x8)(__bf16)(float)bb[j][pt]; }
+      return;
 #endif
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][0]) : "v"(wa32), "i"(j * TB + ks * 2048));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][1]) : "v"(wa32), "i"(j * TB + ks * 2048 + 512));
 #pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) {
-#if AZ_TOWER_ABLATE == 2
-          bf16x8 b = a0;
-          b[0] = (__bf16)(float)(q[pt] + sw[pt]);
-#else
-          const bf16x8 b = *(const bf16x8 *)(act + (on[pt] ? q[pt] + ((chunk ^ sw[pt]) << 4) : ZERO_OFF));
-#endif
-#if AZ_TOWER_ABLATE == 1  // diagnostic build: LDS fragment reads kept alive, no MFMAs
-          asm volatile("" ::"v"(a0), "v"(a1), "v"(b));
-#else
-          acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[pt][0], 0, 0, 0);
-          acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[pt][1], 0, 0, 0);
-#endif
-        }
+      for (int pt = 0; pt < NPT; ++pt)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][pt]) : "v"(act32 + (bb[j][pt] ^ (uint32_t)(ks << 5))));
+    };
+    load(0, 0);
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      if (i + 1 < NK) {
+        load(i + 1, (i + 1) & 1);
+        if (NPT == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // step i's 2 + NPT reads have returned
+        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+#if AZ_TOWER_ABLATE == 1  // diagnostic build: LDS fragment reads kept alive, no MFMAs
+        asm volatile("" ::"v"(fa[i & 1][0]), "v"(fa[i & 1][1]), "v"(fb[i & 1][pt]));
+#else
+        acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][0], fb[i & 1][pt], acc[pt][0], 0, 0, 0);
+        acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][1], fb[i & 1][pt], acc[pt][1], 0, 0, 0);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next stage has landed
     __syncthreads();  // after the last stage: every wave has finished reading act -> the epilogue may overwrite it
@@ -161,39 +184,59 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
   buf = (buf + NSTAGE) & 1;
 }
 
-// bias (+ residual) + ReLU, bf16, written back in place
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+
+// two f32 -> packed bf16 (one v_cvt_pk_bf16_f32), then ReLU on the packed pair as a signed 16-bit max with 0
+// (a negative bf16 has its sign bit set, i.e. is a negative int16): one v_pk_max_i16 for two values
+__device__ __forceinline__ uint32_t pack_relu(float a, float b) {
+  const bf16x2 t = __builtin_convertvector((f32x2){a, b}, bf16x2);
+  const i16x2 z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, t), z));
+}
+
+// accumulators start at the layer's bias (+ the block's residual): the epilogue is then only ReLU + pack + store.
+// The 8 bias reads go out back to back (one LDS round trip per layer, not one per 4 values).
 template <bool RES, int NPT>
-__device__ __forceinline__ void epilogue(char *act, const float *bias, int lane, const int (&pp)[NPT], const bool (&ok)[NPT],
-                                         const f32x16 (&acc)[NPT][2], const uint2 (&res)[NPT][2][4]) {
-  const int h = lane >> 5;
+__device__ __forceinline__ void init_acc(const float *bias, int lane, f32x16 (&acc)[NPT][2], const uint2 (&res)[NPT][2][4]) {
+  const int h = fresh(lane) >> 5;
+  float4 bv[2][4];
 #pragma unroll
-  for (int pt = 0; pt < NPT; ++pt) {
-    if (!ok[pt]) continue;
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[ct][q] = *(const float4 *)(bias + ct * 32 + q * 8 + h * 4);
+#pragma unroll
+  for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 bv = *(const float4 *)(bias + ct * 32 + q * 8 + h * 4);
-        float v0 = acc[pt][ct][4 * q + 0] + bv.x, v1 = acc[pt][ct][4 * q + 1] + bv.y;
-        float v2 = acc[pt][ct][4 * q + 2] + bv.z, v3 = acc[pt][ct][4 * q + 3] + bv.w;
+        float v0 = bv[ct][q].x, v1 = bv[ct][q].y, v2 = bv[ct][q].z, v3 = bv[ct][q].w;
         if (RES) {
           const uint2 rr = res[pt][ct][q];
           v0 += bf_lo(rr.x); v1 += bf_hi(rr.x); v2 += bf_lo(rr.y); v3 += bf_hi(rr.y);
         }
-        v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
-        *(uint2 *)(act + act_addr(pp[pt], ct * 4 + q) + 8 * h) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+        acc[pt][ct][4 * q + 0] = v0; acc[pt][ct][4 * q + 1] = v1; acc[pt][ct][4 * q + 2] = v2; acc[pt][ct][4 * q + 3] = v3;
       }
-  }
 }
 
+// ReLU, bf16, written back in place
 template <int NPT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NPT][2]) {
+__device__ __forceinline__ void epilogue(char *act, int lane, const int (&pp)[NPT], const bool (&ok)[NPT],
+                                         const f32x16 (&acc)[NPT][2]) {
+  const int h = fresh(lane) >> 5;
 #pragma unroll
-  for (int a = 0; a < NPT; ++a)
+  for (int pt = 0; pt < NPT; ++pt) {
+    if (!ok[pt]) continue;
+    const int pe = fresh(pp[pt]);
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+      for (int q = 0; q < 4; ++q)
+        *(uint2 *)(act + act_addr(pe, ct * 4 + q) + 8 * h) =
+            make_uint2(pack_relu(acc[pt][ct][4 * q + 0], acc[pt][ct][4 * q + 1]), pack_relu(acc[pt][ct][4 * q + 2], acc[pt][ct][4 * q + 3]));
+  }
 }
 
 // async global -> LDS copy of 4 B per lane
@@ -221,7 +264,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   float *hw = (float *)(wbuf + 2 * STAGE_BYTES);  // 3*64 + 3 floats
   char *rgb = wbuf + 2 * STAGE_BYTES + HW_BYTES;  // 2 x {RGW ring words, BPW player words}
   float *bl = (float *)(rgb + 2 * RG_STRIDE);     // (1+L)*64 biases
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   for (int i = tid; i < Q::ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero slot
   for (int i = tid; i < 3 * CH + 3; i += 256) hw[i] = i < 3 * CH ? headw[i] : headb[i - 3 * CH];
@@ -290,7 +333,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     // (8 bitboard states per board + the player to move), expanded here
     const uint32_t *rg = (const uint32_t *)(rgb + inb * RG_STRIDE);
     const int *slots = (const int *)rg + RGW + BPW;
-    for (int m = tid; m < Q::NVT; m += 256) {
+    for (int m = fresh(tid); m < Q::NVT; m += 256) {
       const int b = m / Q::NV, cell = m % Q::NV, g = slots[b];
       uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (g >= 0) {
@@ -319,56 +362,74 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     f32x16 acc[NPT][2];
     uint2 res[NPT][2][4];
     // ---- stem
-    zero_acc(acc);
+    init_acc<false, NPT>(bl, lane, acc, res);
     if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
     else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, has_next ? w0 : nullptr, tid, lane, pp, vm, acc);
-    epilogue<false, NPT>(act, bl, lane, pp, ok, acc, res);
+    epilogue<NPT>(act, lane, pp, ok, acc);
     __syncthreads();
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
-      const int h = lane >> 5;
+      const int h = fresh(lane) >> 5;
 #pragma unroll
-      for (int pt = 0; pt < NPT; ++pt)
+      for (int pt = 0; pt < NPT; ++pt) {
+        const int pe = fresh(pp[pt]);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pp[pt], ct * 4 + q) + 8 * h);
-      zero_acc(acc);
+          for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pe, ct * 4 + q) + 8 * h);
+      }
+      init_acc<false, NPT>(bl + (1 + l) * CH, lane, acc, res);
       conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
                                        lane, pp, vm, acc);
-      epilogue<false, NPT>(act, bl + (1 + l) * CH, lane, pp, ok, acc, res);
+      epilogue<NPT>(act, lane, pp, ok, acc);
       __syncthreads();
-      zero_acc(acc);
+      init_acc<true, NPT>(bl + (2 + l) * CH, lane, acc, res);
       if (l + 2 < L)
         conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
                                          tid, lane, pp, vm, acc);
       else  // last layer of this board: prefetch the next board's stem weights
         conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, has_next ? w0 : nullptr, tid, lane,
                                          pp, vm, acc);
-      epilogue<true, NPT>(act, bl + (2 + l) * CH, lane, pp, ok, acc, res);
+      epilogue<NPT>(act, lane, pp, ok, acc);
       __syncthreads();
     }
-    // ---- heads: 1x1 convs (+folded BN) + ReLU, one position per thread
-    for (int m = tid; m < Q::NVT; m += 256) {
-      const int b = m / Q::NV, cell = m % Q::NV, g = slots[b];
-      if (g < 0) continue;
-      float s0 = hw[3 * CH + 0], s1 = hw[3 * CH + 1], s2 = hw[3 * CH + 2];
+    // ---- heads: the three 1x1 convs (+folded BN) + ReLU as one more implicit GEMM: rows 0..2 of a 32-row A tile
+    // are the head filters (built here from the f32 table in LDS, bf16), the B fragments are the centre tap of the
+    // trunk output; lanes 0..31 end up with their cell's three outputs in accumulator registers 0..2
+    {
+      const int hl = fresh(lane), h = hl >> 5, r = hl & 31;
+      f32x16 hacc[NPT];
 #pragma unroll
-      for (int chunk = 0; chunk < 8; ++chunk) {
-        const uint4 u = *(const uint4 *)(act + act_addr(m, chunk));
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+      for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float lo = bf_lo(w[k]), hi = bf_hi(w[k]);
-          const int c = chunk * 8 + 2 * k;
-          s0 += lo * hw[c] + hi * hw[c + 1];
-          s1 += lo * hw[CH + c] + hi * hw[CH + c + 1];
-          s2 += lo * hw[2 * CH + c] + hi * hw[2 * CH + c + 1];
+        for (int i = 0; i < 16; ++i) hacc[pt][i] = 0.0f;
+      const int pe0 = fresh(pp[0]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 a;
+        const float *wr = hw + (r < 3 ? r : 0) * CH + ks * 16 + 8 * h;
+        const float4 w0v = *(const float4 *)wr, w1v = *(const float4 *)(wr + 4);
+        const float m = r < 3 ? 1.0f : 0.0f;
+        a[0] = (__bf16)(w0v.x * m); a[1] = (__bf16)(w0v.y * m); a[2] = (__bf16)(w0v.z * m); a[3] = (__bf16)(w0v.w * m);
+        a[4] = (__bf16)(w1v.x * m); a[5] = (__bf16)(w1v.y * m); a[6] = (__bf16)(w1v.z * m); a[7] = (__bf16)(w1v.w * m);
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+          const int pe = pt == 0 ? pe0 : fresh(pp[pt]);
+          const bf16x8 b = *(const bf16x8 *)(act + act_addr(pe, ks * 2 + h));
+          hacc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, hacc[pt], 0, 0, 0);
         }
       }
-      pfeat[(size_t)g * Q::NV + cell] = fmaxf(s0, 0.0f);
-      vfeat[((size_t)g * 2 + 0) * Q::NV + cell] = fmaxf(s1, 0.0f);
-      vfeat[((size_t)g * 2 + 1) * Q::NV + cell] = fmaxf(s2, 0.0f);
+      if (h == 0) {
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+          if (!ok[pt]) continue;
+          const int m = fresh(pp[pt]), b = m / Q::NV, cell = m % Q::NV, g = slots[b];
+          if (g < 0) continue;
+          pfeat[(size_t)g * Q::NV + cell] = fmaxf(hacc[pt][0] + hw[3 * CH + 0], 0.0f);
+          vfeat[((size_t)g * 2 + 0) * Q::NV + cell] = fmaxf(hacc[pt][1] + hw[3 * CH + 1], 0.0f);
+          vfeat[((size_t)g * 2 + 1) * Q::NV + cell] = fmaxf(hacc[pt][2] + hw[3 * CH + 2], 0.0f);
+        }
+      }
     }
     __syncthreads();  // heads done reading before the next group's input overwrites act
   }
