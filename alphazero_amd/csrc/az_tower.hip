@@ -74,6 +74,16 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
                                    (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)lds_base, 16, 0, 0);
 }
 
+// Diagnostic build only (-DAZ_TOWER_STAMP=1, wrong outputs): wave-level s_memtime stamps of one steady-state group of
+// block 7, written over the start of vfeat as u64[4 waves][32].  The product build executes no stamp.
+#ifndef AZ_TOWER_STAMP
+#define AZ_TOWER_STAMP 0
+#endif
+#if AZ_TOWER_STAMP
+#define STAMP(k) do { if (stamp_on) tsv[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 #ifndef AZ_TOWER_ABLATE
 #define AZ_TOWER_ABLATE 0  // 0 = product; 1 / 2 = timing diagnostics only (wrong results)
 #endif
@@ -87,6 +97,9 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 #endif
 #ifndef AZ_TOWER9_ST
 #define AZ_TOWER9_ST 1  // 9x9 (3 boards per workgroup): per-tap staging keeps two workgroups within a CU's 160 KiB of LDS
+#endif
+#ifndef AZ_TOWER_PREFETCH
+#define AZ_TOWER_PREFETCH 1  // k-steps (of 2 + NPT fragment reads) issued ahead of the MFMAs that consume them
 #endif
 #ifndef AZ_TOWER_WAVES_PER_SIMD
 #define AZ_TOWER_WAVES_PER_SIMD 2
@@ -117,7 +130,7 @@ __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave,
 template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST>
 __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext,
                                            int tid, int lane, const int (&pp)[NPT], const uint32_t (&vm)[NPT],
-                                           f32x16 (&acc)[NPT][2]) {
+                                           f32x16 (&acc)[NPT][2], unsigned long long *twait = nullptr) {
   constexpr int TB = KS * 2048;  // bytes per tap
   constexpr int NSTAGE = 9 / ST, STAGE_BYTES = ST * TAP_BYTES, NK = ST * KS;
   const int h = lane >> 5, r = lane & 31, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,12 +155,14 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
     }
     // Fragment reads are inline asm with hand-counted waits: hipcc's own ds_read + MFMA schedule here reads each
     // fragment just before its MFMA and waits lgkmcnt(0) every time (one exposed LDS round trip per two MFMAs).
-    bf16x8 fa[2][2], fb[2][NPT];
+    constexpr int PD = AZ_TOWER_PREFETCH < NK ? AZ_TOWER_PREFETCH : NK - 1;  // k-steps of fragments in flight ahead of the MFMAs
+    constexpr int NS = PD + 1;
+    bf16x8 fa[NS][2], fb[NS][NPT];
     const uint32_t wa32 = (uint32_t)(uintptr_t)wa, act32 = (uint32_t)(uintptr_t)act;
     auto load = [&](int i, int s) {
       const int j = i / KS, ks = i % KS;
 #if AZ_TOWER_ABLATE == 2  // diagnostic build: MFMAs on register operands, no LDS fragment reads
-      if (i < 2) { fa[s][0] = fa[s][1] = (bf16x8)(__bf16)1.0f; for (int pt = 0; pt < NPT; ++pt) fb[s][pt] = (bf16x8)(__bf16)(float)bb[j][pt]; }
+      if (i < NS) { fa[s][0] = fa[s][1] = (bf16x8)(__bf16)1.0f; for (int pt = 0; pt < NPT; ++pt) fb[s][pt] = (bf16x8)(__bf16)(float)bb[j][pt]; }
       return;
 #endif
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][0]) : "v"(wa32), "i"(j * TB + ks * 2048));
@@ -156,30 +171,41 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
       for (int pt = 0; pt < NPT; ++pt)
         asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][pt]) : "v"(act32 + (bb[j][pt] ^ (uint32_t)(ks << 5))));
     };
-    load(0, 0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) load(i, i);
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
-      if (i + 1 < NK) {
-        load(i + 1, (i + 1) & 1);
-        if (NPT == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // step i's 2 + NPT reads have returned
-        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (i + PD < NK) load(i + PD, (i + PD) % NS);
+      {  // wait until step i's 2 + NPT reads have returned: everything issued after them may still be in flight
+        constexpr int RPS = 2 + NPT;
+        const int ahead = (NK - 1 - i < PD ? NK - 1 - i : PD) * RPS;
+        if (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if (ahead == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else if (ahead == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else if (ahead == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pt = 0; pt < NPT; ++pt) {
 #if AZ_TOWER_ABLATE == 1  // diagnostic build: LDS fragment reads kept alive, no MFMAs
-        asm volatile("" ::"v"(fa[i & 1][0]), "v"(fa[i & 1][1]), "v"(fb[i & 1][pt]));
+        asm volatile("" ::"v"(fa[i % NS][0]), "v"(fa[i % NS][1]), "v"(fb[i % NS][pt]));
 #else
-        acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][0], fb[i & 1][pt], acc[pt][0], 0, 0, 0);
-        acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][1], fb[i & 1][pt], acc[pt][1], 0, 0, 0);
+        acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % NS][0], fb[i % NS][pt], acc[pt][0], 0, 0, 0);
+        acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % NS][1], fb[i % NS][pt], acc[pt][1], 0, 0, 0);
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#if AZ_TOWER_STAMP
+    const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next stage has landed
     __syncthreads();  // after the last stage: every wave has finished reading act -> the epilogue may overwrite it
+#if AZ_TOWER_STAMP
+    if (twait) *twait += __builtin_amdgcn_s_memtime() - tw0;
+#endif
   }
   buf = (buf + NSTAGE) & 1;
 }
@@ -326,8 +352,17 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+#if AZ_TOWER_STAMP
+  unsigned long long tsv[32];
+  for (int k = 0; k < 32; ++k) tsv[k] = 0;
+#endif
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x, ++it) {
     const bool has_next = grp + (int)gridDim.x < ngroups;
+#if AZ_TOWER_STAMP
+    const bool stamp_on = blockIdx.x == 7 && it == 5;
+    unsigned long long tw = 0;
+#endif
+    STAMP(0);
     if (has_next) stage_input(it + 1, inb ^ 1);  // lands under this group's tower
     // ---- input -> act[cell][0..15] (channels 9..15 zero): the NCHW bf16 planes, or the packed leaf batch
     // (8 bitboard states per board + the player to move), expanded here
@@ -358,6 +393,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     }
     inb ^= 1;
     __syncthreads();
+    STAMP(1);
 
     f32x16 acc[NPT][2];
     uint2 res[NPT][2][4];
@@ -365,8 +401,10 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     init_acc<false, NPT>(bl, lane, acc, res);
     if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
     else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, has_next ? w0 : nullptr, tid, lane, pp, vm, acc);
+    STAMP(2);
     epilogue<NPT>(act, lane, pp, ok, acc);
     __syncthreads();
+    STAMP(3);
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
       const int h = fresh(lane) >> 5;
@@ -378,20 +416,35 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
 #pragma unroll
           for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pe, ct * 4 + q) + 8 * h);
       }
+#if AZ_TOWER_STAMP
+      const int sk = 4 + (l & 2) * 4;
+      unsigned long long *twp = &tw;
+#else
+      unsigned long long *twp = nullptr;
+#endif
       init_acc<false, NPT>(bl + (1 + l) * CH, lane, acc, res);
+      STAMP(sk + 0);
       conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
-                                       lane, pp, vm, acc);
+                                       lane, pp, vm, acc, twp);
+      STAMP(sk + 1);
       epilogue<NPT>(act, lane, pp, ok, acc);
       __syncthreads();
+      STAMP(sk + 2);
       init_acc<true, NPT>(bl + (2 + l) * CH, lane, acc, res);
+      STAMP(sk + 3);
       if (l + 2 < L)
         conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
-                                         tid, lane, pp, vm, acc);
+                                         tid, lane, pp, vm, acc, twp);
       else  // last layer of this board: prefetch the next board's stem weights
         conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, has_next ? w0 : nullptr, tid, lane,
-                                         pp, vm, acc);
+                                         pp, vm, acc, twp);
+      STAMP(sk + 4);
       epilogue<NPT>(act, lane, pp, ok, acc);
       __syncthreads();
+      STAMP(sk + 5);
+#if AZ_TOWER_STAMP
+      if (stamp_on) tsv[sk + 6] = tw;
+#endif
     }
     // ---- heads: the three 1x1 convs (+folded BN) + ReLU as one more implicit GEMM: rows 0..2 of a 32-row A tile
     // are the head filters (built here from the f32 table in LDS, bf16), the B fragments are the centre tap of the
@@ -431,7 +484,13 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
         }
       }
     }
+    STAMP(28);
     __syncthreads();  // heads done reading before the next group's input overwrites act
+    STAMP(29);
+#if AZ_TOWER_STAMP
+    if (stamp_on && lane == 0)
+      for (int k = 0; k < 32; ++k) ((unsigned long long *)vfeat)[wave * 32 + k] = tsv[k];
+#endif
   }
 }
 

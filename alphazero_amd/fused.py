@@ -60,6 +60,7 @@ class FusedTowerEvaluator:
         self.n2 = model._policy_head[4].in_features
         self.board = 15 if self.n2 == 225 else 9
         self._buf = {}
+        self.kernel_events = None  # bench.py sets this to a list: (start, end) HIP events around the tower kernel alone
         self.refresh()
 
     @torch.no_grad()
@@ -108,12 +109,18 @@ class FusedTowerEvaluator:
             self._buf[B] = (torch.zeros(B, self.n2, device=self.device), torch.zeros(B, 2 * self.n2, device=self.device))
         pfeat, vfeat = self._buf[B]
         P = lambda t: C.c_void_p(t.data_ptr())
+        if self.kernel_events is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         rc = self.lib.az_tower_forward(self.board, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
                                        list_p, count_p, P(self.w0), P(self.wl), P(self.bias),
                                        P(self.headw), P(self.headb), P(pfeat), P(vfeat),
                                        C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:
             raise EngineError(f"az_tower_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
+        if self.kernel_events is not None:
+            ev1.record()
+            self.kernel_events.append((ev0, ev1))
         logits = torch.addmm(self.pl_b, pfeat, self.pl_wt, out=logits_out) if logits_out is not None \
             else torch.addmm(self.pl_b, pfeat, self.pl_wt)
         hid = torch.relu_(torch.addmm(self.v1_b, vfeat, self.v1_wt))

@@ -12,10 +12,14 @@ emission of finished games' (state, pi, z) samples into a pinned host ring, slot
 So one step = slots x 400 simulations per GPU.  Inputs live in HBM; only finished samples cross PCIe.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant hand-written tree kernel (k_select_gather): algorithmic bytes per launch
-                  / mean launch time measured with HIP events on the launch stream, vs 8 TB/s HBM.
-  nn_eval      -- the network forward (fused MFMA tower az_tower.hip, or PyTorch/MIOpen with --evaluator model):
-                  achieved TFLOP/s vs 2.5 PFLOP/s dense bf16.
+  roofline     -- the dominant kernel of the step.  With the fused evaluator that is the conv tower (k_tower, MFMA
+                  bound): the convolutions' algorithmic flops for the boards one launch evaluates / mean launch time
+                  (HIP events on the launch stream around the kernel alone), vs 2.5 PFLOP/s dense bf16.  Otherwise the
+                  slower tree kernel (HBM bound).
+  roofline_tree-- the slower hand-written tree kernel (k_select_gather / k_expand_backup): algorithmic bytes per
+                  launch / mean launch time, vs 8 TB/s HBM.
+  nn_eval      -- the whole network forward (tower + head linears, or PyTorch/MIOpen with --evaluator model):
+                  achieved TFLOP/s on the boards actually evaluated vs 2.5 PFLOP/s dense bf16.
   cpu_baseline -- the CPU oracle (oracle/, "port" of the reference path, proven equal to it on the
                   golden fixtures) timed on this box's host cores with the same network on torch-CPU.
 """
@@ -215,10 +219,12 @@ def main():
         run.num_sims = sims
         eng.check()
 
-    ev_sel, ev_exp, ev_nn = [], [], []
+    ev_sel, ev_exp, ev_nn, ev_tower = [], [], [], []
 
     def timed_round():
         """run.move_round with HIP events around each tree kernel and each network forward"""
+        if run.fused is not None:
+            run.fused.kernel_events = ev_tower  # events around the tower kernel alone, inside FusedTowerEvaluator
         noise = run.draw_noise()
         eng.begin_search()
         for _ in range(sims):
@@ -231,6 +237,8 @@ def main():
             eng.expand_backup(run.logits, run.values, noise)
             e2.record()
             ev_sel.append((a, b)); ev_nn.append((b, c)); ev_exp.append((c, e2))
+        if run.fused is not None:
+            run.fused.kernel_events = None
         run.draw_expo()
         eng.play_moves(inv_tao, run.expo, None, run.actions, run.done)
         return run.done
@@ -302,19 +310,50 @@ def main():
         exp_bytes = (st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 20.0 * st["expanded_edges"]
                      + 32.0 * st["sum_depth"] + 36.0 * st["sims"]) / launches
         dom = ("k_select_gather", sel_bytes, sel_ms) if sel_ms >= exp_ms else ("k_expand_backup", exp_bytes, exp_ms)
+
         # HBM traffic from PMC counters cannot be collected inside this run (separate rocprofv3 --pmc passes,
         # scripts/pmc_traffic.sh); the last committed measurement of this same workload is reported, if present
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-        if args.workload == "gomoku15" and args.evaluator == "fused" and os.path.exists(tpath):
+        def pmc_traffic(kernel):
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+            if args.workload != "gomoku15" or args.evaluator != "fused" or not os.path.exists(tpath):
+                return None, None
             try:
-                t = json.load(open(tpath))[dom[0]]
-                traffic = t["FETCH_SIZE"]["corrected_bytes_per_launch"] + t["WRITE_SIZE"]["corrected_bytes_per_launch"]
-                traffic_note = ("bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from separate --pmc passes "
-                                "(scripts/pmc_traffic.sh -> profiles/pmc_traffic_latest.json)")
+                t = json.load(open(tpath))[kernel]
+                return (t["FETCH_SIZE"]["corrected_bytes_per_launch"] + t["WRITE_SIZE"]["corrected_bytes_per_launch"],
+                        "bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from separate --pmc passes "
+                        "(scripts/pmc_traffic.sh -> profiles/pmc_traffic_latest.json)")
             except Exception:
-                traffic = None
+                return None, None
+
+        traffic, traffic_note = pmc_traffic(dom[0])
         achieved = dom[1] / (dom[2] * 1e-3) / 1e9 if dom[2] > 0 else 0.0
+        tree_roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": dom[1],
+                         "ms_per_launch": dom[2]}
+        evals_per_launch = st["evals"] / launches  # boards the network really evaluates per simulation step
+        roofline = tree_roofline
+        nn_eval = None
+        if args.evaluator in ("model", "fused") and hasattr(model, "flops_per_eval"):
+            import torch.nn as tnn
+            conv_flops = sum(2.0 * d.height * d.width * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
+                             for m in model.modules() if isinstance(m, tnn.Conv2d))
+            fl = model.flops_per_eval() * evals_per_launch
+            nn_eval = {"bound": "mfma", "ms_per_batch": nn_ms, "achieved": fl / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
+                       "peak": 2500.0, "unit": "TFLOP/s", "frac": (fl / (nn_ms * 1e-3) / 1e12 / 2500.0) if nn_ms else 0.0,
+                       "flops_per_eval": model.flops_per_eval(), "boards_per_batch": evals_per_launch,
+                       "share_of_step": nn_ms / max(nn_ms + sel_ms + exp_ms, 1e-9),
+                       "implementation": "az_tower.hip fused bf16 MFMA tower + torch head linears" if args.evaluator == "fused"
+                       else "PyTorch/MIOpen module forward"}
+            if args.evaluator == "fused" and ev_tower:
+                # the dominant kernel of the step: the fused conv tower (MFMA bound).  Algorithmic flops = the convolutions'
+                # multiply-adds x 2 for the boards this launch evaluates (terminal leaves are skipped, padding is not counted)
+                tw_ms = mean_ms(ev_tower)
+                tw_fl = conv_flops * evals_per_launch
+                ttraffic, tnote = pmc_traffic("k_tower")
+                roofline = {"bound": "mfma", "kernel": "k_tower", "achieved": tw_fl / (tw_ms * 1e-3) / 1e12, "peak": 2500.0,
+                            "unit": "TFLOP/s", "frac": tw_fl / (tw_ms * 1e-3) / 1e12 / 2500.0, "traffic": ttraffic,
+                            "traffic_note": tnote, "flops_per_launch": tw_fl, "boards_per_launch": evals_per_launch,
+                            "ms_per_launch": tw_ms, "share_of_step": tw_ms / max(nn_ms + sel_ms + exp_ms, 1e-9)}
         out = {
             "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -324,9 +363,8 @@ def main():
                        "slots_per_gpu": slots, "sims_per_move": sims, "parallelism": f"games sharded x{world}, no data-path collective"},
             "games_per_sec": total_games / elapsed, "plies_per_sec": slots * world * args.steps / elapsed,
             "mean_plies_per_finished_game": (total_plies / total_games) if total_games else None,
-            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": dom[1],
-                         "ms_per_launch": dom[2]},
+            "roofline": roofline,
+            "roofline_tree": tree_roofline,
             "tree_kernels": {"k_select_gather": {"ms": sel_ms, "bytes": sel_bytes, "GBps": sel_bytes / max(sel_ms, 1e-9) / 1e6},
                              "k_expand_backup": {"ms": exp_ms, "bytes": exp_bytes, "GBps": exp_bytes / max(exp_ms, 1e-9) / 1e6},
                              "event_pair_overhead_ms": ev_overhead,
@@ -337,13 +375,8 @@ def main():
                              "evals_per_sim": st["evals"] / max(st["sims"], 1)},
             "cpu_baseline": cpu,
         }
-        if args.evaluator in ("model", "fused") and hasattr(model, "flops_per_eval"):
-            fl = model.flops_per_eval() * slots
-            out["nn_eval"] = {"bound": "mfma", "ms_per_batch": nn_ms, "achieved": fl / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
-                              "peak": 2500.0, "unit": "TFLOP/s", "frac": (fl / (nn_ms * 1e-3) / 1e12 / 2500.0) if nn_ms else 0.0,
-                              "flops_per_eval": model.flops_per_eval(), "share_of_step": nn_ms / max(nn_ms + sel_ms + exp_ms, 1e-9),
-                              "implementation": "az_tower.hip fused bf16 MFMA tower + torch head linears" if args.evaluator == "fused"
-                              else "PyTorch/MIOpen module forward"}
+        if nn_eval is not None:
+            out["nn_eval"] = nn_eval
         if cpu:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
         print(json.dumps(out))
