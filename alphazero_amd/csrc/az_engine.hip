@@ -191,11 +191,42 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
   const int used = v.edgeCnt[g];
   int nParent = v.rootN[g];
   const uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
-  load_ring<GT>(tb, ply, hist, lane);
-  if (lane < GT::SW) cur[lane] = tb[(size_t)ply * GT::SW + lane];
+  const size_t eb = (size_t)g * v.E;
+
+  // A node's block is read with ALL its loads in flight at once (a lane owns records lane, lane + 64, ...; indices past
+  // the block are clamped to its last record and ignored), so a tree level costs one memory round trip; the root's block
+  // is requested before the history ring is staged, so that it travels together with the ring and the board.
+  constexpr int NI = (GT::A + 63) / 64;
+  double eq[NI];
+  int2 epn[NI];
+  uint32_t em[NI];
+  auto fetch = [&](int base, int cnt) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int i = min(lane + 64 * k, cnt - 1);
+      const size_t e = eb + base + i;
+      eq[k] = v.edgeQ[e];
+      epn[k] = v.edgePN[e];
+      em[k] = v.edgeMeta[e];
+    }
+  };
+  constexpr int RW = (8 * GT::SW + 63) / 64;  // ring words per lane
+  uint32_t rw[RW];
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    const int i = lane + 64 * k, hk = i / GT::SW, w = i % GT::SW, t = ply - 7 + hk;
+    rw[k] = (i < 8 * GT::SW && t >= 0) ? tb[(size_t)t * GT::SW + w] : 0u;
+  }
+  const uint32_t cw = lane < GT::SW ? tb[(size_t)ply * GT::SW + lane] : 0u;
+  if (used > 0) fetch(0, GT::PMAX - ply);
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    const int i = lane + 64 * k;
+    if (i < 8 * GT::SW) hist[i / GT::SW][i % GT::SW] = rw[k];
+  }
+  if (lane < GT::SW) cur[lane] = cw;
   __syncthreads();
 
-  const size_t eb = (size_t)g * v.E;
   int head = 0, depth = 0, kind = KIND_EVAL, base = 0;
   float tval = 0.0f;
   unsigned long long scanned = 0;
@@ -207,15 +238,13 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
       float best = -INFINITY;
       int bestIdx = 0x7fffffff, bestN = 0;
       uint32_t bestMeta = 0;
-      for (int i = lane; i < cnt; i += 64) {
-        const size_t e = eb + base + i;
-        const double q = v.edgeQ[e];
-        const int2 pn = v.edgePN[e];
-        const uint32_t m = v.edgeMeta[e];
-        const double qs = (m & META_SAME) ? q : -q;
-        const float u = ((v.c_puct * __int_as_float(pn.x)) * sqrtN) / (float)(pn.y + 1);
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int i = lane + 64 * k;
+        const double qs = (em[k] & META_SAME) ? eq[k] : -eq[k];
+        const float u = ((v.c_puct * __int_as_float(epn[k].x)) * sqrtN) / (float)(epn[k].y + 1);
         const float sc = (float)qs + u;
-        if (sc > best) { best = sc; bestIdx = i; bestMeta = m; bestN = pn.y; }
+        if (i < cnt && sc > best) { best = sc; bestIdx = i; bestMeta = em[k]; bestN = epn[k].y; }
       }
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
@@ -232,6 +261,7 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
       if (bestIdx >= cnt) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
       const int a = (int)(meta & META_ACT);
       const int kid = (int)(meta >> META_KID_SHIFT);
+      if (kid) fetch(kid - 1, cnt - 1);  // the child's block: on its way while the move is replayed on the board
       if (lane == 0) v.path[(size_t)g * v.D + depth] = base + bestIdx;
       ++depth;
       const int mover = pl;

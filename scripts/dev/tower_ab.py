@@ -19,6 +19,8 @@ torch.manual_seed(0)
 net = GomokuNet(board, 64, blocks).eval().cuda()
 ev = FusedTowerEvaluator(net)
 x = torch.randint(-1, 2, (B, 9, board, board), device="cuda").to(torch.bfloat16)
+if os.environ.get("ZERO"):  # all-zero weights and inputs: same instruction stream, minimal switching power
+    ev.w0.zero_(); ev.wl.zero_(); x.zero_()
 ref_p, ref_v = ev(x)
 ref_p, ref_v = ref_p.clone(), ref_v.clone()
 pfeat, vfeat = ev._buf[B]
