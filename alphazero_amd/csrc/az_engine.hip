@@ -3,7 +3,8 @@
 // Data layout in HBM (all owned by the engine, allocated once in az_create):
 //   per tree g (one per game slot), a bump-allocated pool of CHILD RECORDS ("edges"), struct of arrays,
 //   tree-major so that the children of one node are one contiguous, coalesced run:
-//     edgeQ    f64  [G][E]   child.value (running mean, the child's own point of view)
+//     edgeQ    f64  [G][E]   child.value (running mean, the child's own point of view); NOT written at expansion:
+//                            a record with visits == 0 has value 0.0 by definition, whatever the bytes say
 //     edgePN   2x32 [G][E]   {prior of the child (the parent's prior[0, action]) f32, child.visits i32}
 //     edgeMeta u32  [G][E]   action (bits 0-8) | child.player == parent.player (bit 9) |
 //                            1 + first edge of the child's own block once it is expanded (bits 10-31)
@@ -183,13 +184,14 @@ __device__ __forceinline__ void load_ring(const uint32_t *tb, int ply, uint32_t 
 template <class GT, typename OutT>
 __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
   const int g = blockIdx.x, lane = threadIdx.x;
-  if (!v.active[g]) { if (lane == 0) v.evalFlag[g] = 0; return; }
   __shared__ uint32_t hist[8][GT::SW];
   __shared__ uint32_t cur[GT::SW];
+  const bool slotActive = v.active[g] != 0;  // one batch with the other per-slot words
   const int ply = v.ply[g];
   int pl = v.player[g];
   const int used = v.edgeCnt[g];
   int nParent = v.rootN[g];
+  if (!slotActive) { if (lane == 0) v.evalFlag[g] = 0; return; }
   const uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
   const size_t eb = (size_t)g * v.E;
 
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
         const int i = lane + 64 * k;
-        const double qs = (em[k] & META_SAME) ? eq[k] : -eq[k];
+        const double q0 = epn[k].y > 0 ? eq[k] : 0.0;  // unvisited: child.value is still its initial 0.0 (never stored)
+        const double qs = (em[k] & META_SAME) ? q0 : -q0;
         const float u = ((v.c_puct * __int_as_float(epn[k].x)) * sqrtN) / (float)(epn[k].y + 1);
         const float sc = (float)qs + u;
         if (i < cnt && sc > best) { best = sc; bestIdx = i; bestMeta = em[k]; bestN = epn[k].y; }
@@ -328,24 +331,49 @@ template <class GT>
 __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logits, const float *values,
                                                       const float *noise) {
   const int g = blockIdx.x, lane = threadIdx.x;
-  if (!v.active[g]) return;
+  const bool slotActive = v.active[g] != 0;  // tested after the batch below is on its way (all of it is valid memory)
   __shared__ uint32_t st[GT::SW];
-  const int4 lf = v.leaf[g];
-  const int depth = lf.x, kind = lf.y;
+  constexpr int A = GT::A, NI = (A + 63) / 64;
   const size_t eb = (size_t)g * v.E;
   const int32_t *path = v.path + (size_t)g * v.D;
+  // Everything that depends only on the slot is requested up front, in one batch (one memory round trip): the leaf
+  // record, the leaf board, the network's row, the root statistics and the first 64 path entries (entries past the
+  // leaf's depth are stale and ignored).  The second batch is the path's child records; then come the stores.
+  const int4 lf = v.leaf[g];
+  const uint32_t bw = lane < GT::SW ? v.leafRing[((size_t)g * 8 + 7) * GT::SW + lane] : 0u;
+  float p[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int a = lane + 64 * i;
+    p[i] = logits[(size_t)g * A + min(a, A - 1)];
+  }
+  const float nnv = values[g];
+  const int used = v.edgeCnt[g];
+  const int rootN = v.rootN[g];
+  const double rootQ = v.rootQ[g];
+  const int pth = lane < v.D ? path[lane] : 0;
+  if (!slotActive) return;
+  const int depth = lf.x, kind = lf.y;
+  // this lane's path edge (lane j owns path edge depth-1-j), fetched before the expansion's arithmetic
+  const int pj = depth <= 64 ? __shfl(pth, max(depth - 1 - lane, 0), 64) : path[depth - 1 - lane];
+  const bool onPath = lane < depth;
+  const size_t pe = eb + (onPath ? pj : 0);
+  uint32_t pmeta = 0;
+  int2 ppn = make_int2(0, 0);
+  double pq = 0.0;
+  if (onPath) { pmeta = v.edgeMeta[pe]; ppn = v.edgePN[pe]; pq = v.edgeQ[pe]; }
+  if (ppn.y == 0) pq = 0.0;  // first visit: the stored bytes are not a value yet
+
   double val;
   if (kind == KIND_EVAL) {
-    if (lane < GT::SW) st[lane] = v.leafRing[((size_t)g * 8 + 7) * GT::SW + lane];
+    if (lane < GT::SW) st[lane] = bw;
     __syncthreads();
-    constexpr int A = GT::A, NI = (A + 63) / 64;
-    float p[NI];
     bool lg[NI];
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int a = lane + 64 * i;
-      p[i] = a < A ? logits[(size_t)g * A + a] : -INFINITY;
+      if (a >= A) p[i] = -INFINITY;
       mx = fmaxf(mx, p[i]);
     }
     mx = wave_max(mx);
@@ -359,19 +387,23 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
     const float inv = 1.0f / wave_sum(acc);
     const bool mix = (noise != nullptr) && depth == 0;  // node is root_node and use_Dirichlet
     const float keep = (float)(1.0 - (double)v.epsilon);
+    float nz[NI];
+    if (mix) {  // wave-uniform: the Dirichlet row, all of it in one batch
+#pragma unroll
+      for (int i = 0; i < NI; ++i) nz[i] = noise[(size_t)g * A + min(lane + 64 * i, A - 1)];
+    }
     acc = 0.0f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int a = lane + 64 * i;
       float x = p[i] * inv;
-      if (mix && a < A) x = keep * x + v.epsilon * noise[(size_t)g * A + a];
+      if (mix && a < A) x = keep * x + v.epsilon * nz[i];
       lg[i] = a < A && GT::legal(st, a);
       x = x * (lg[i] ? 1.0f : 0.0f);
       p[i] = x;
       acc = acc + x;
     }
     const float tot = wave_sum(acc);
-    const int used = v.edgeCnt[g];
     int nLegal = 0;
     unsigned long long bal[NI];
 #pragma unroll
@@ -384,7 +416,6 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
       if (lg[i]) {
         const int pos = off + __popcll(bal[i] & ((1ull << lane) - 1ull));
         const size_t e = eb + used + pos;
-        v.edgeQ[e] = 0.0;
         v.edgePN[e] = make_int2(__float_as_int(p[i] / tot), 0);
         v.edgeMeta[e] = (uint32_t)a | (GT::same_player(st, a) ? META_SAME : 0u);
       }
@@ -392,16 +423,29 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
     }
     if (lane == 0) {
       v.edgeCnt[g] = used + nLegal;
-      if (depth > 0) v.edgeMeta[eb + path[depth - 1]] |= (uint32_t)(used + 1) << META_KID_SHIFT;
+      // the leaf's own edge is path[depth-1] = lane 0's path edge: link it to its new block
+      if (depth > 0) v.edgeMeta[pe] = pmeta | ((uint32_t)(used + 1) << META_KID_SHIFT);
       v.stat[(size_t)g * 6 + 5] += (unsigned)nLegal;
     }
-    val = (double)values[g];  // value.item()
+    val = (double)nnv;  // value.item()
   } else {
     val = (double)__uint_as_float((uint32_t)lf.z);
   }
   // backup: lane j owns path edge depth-1-j; the value it receives has been negated once for every
   // edge BELOW it whose child is the other player's node.
-  for (int base = 0; base < depth; base += 64) {
+  {
+    const bool flip = onPath && (pmeta & META_SAME) == 0u;
+    const unsigned long long fm = __ballot(flip);
+    if (onPath) {
+      const int below = __popcll(fm & ((1ull << lane) - 1ull));
+      const double x = (below & 1) ? -val : val;
+      const int n = ppn.y + 1;
+      v.edgePN[pe].y = n;
+      v.edgeQ[pe] = pq + (x - pq) / (double)n;
+    }
+    if (__popcll(fm) & 1) val = -val;
+  }
+  for (int base = 64; base < depth; base += 64) {  // paths deeper than one wave (never at these board sizes' usual depths)
     const int j = base + lane;
     bool flip = false;
     size_t e = 0;
@@ -415,17 +459,16 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
       const double x = (below & 1) ? -val : val;
       int *np = &v.edgePN[e].y;
       const int n = *np + 1;
-      const double q = v.edgeQ[e];
+      const double q = n > 1 ? v.edgeQ[e] : 0.0;
       *np = n;
       v.edgeQ[e] = q + (x - q) / (double)n;
     }
     if (__popcll(fm) & 1) val = -val;
   }
   if (lane == 0) {
-    const int n = v.rootN[g] + 1;
-    const double q = v.rootQ[g];
+    const int n = rootN + 1;
     v.rootN[g] = n;
-    v.rootQ[g] = q + (val - q) / (double)n;
+    v.rootQ[g] = rootQ + (val - rootQ) / (double)n;
   }
 }
 
@@ -457,7 +500,7 @@ __global__ __launch_bounds__(64) void k_root_policy(View v, float *pi, int32_t *
     const int2 pn = k ? v.edgePN[e] : make_int2(0, 0);
     if (pi) pi[o] = k ? (float)pn.y / tot : 0.0f;
     if (visits) visits[o] = pn.y;
-    if (childQ) childQ[o] = k ? v.edgeQ[e] : 0.0;
+    if (childQ) childQ[o] = (k && pn.y > 0) ? v.edgeQ[e] : 0.0;
     if (rootPrior) rootPrior[o] = __int_as_float(pn.x);
   }
 }

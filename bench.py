@@ -302,12 +302,13 @@ def main():
         launches = max(len(ev_sel), 1)
         sel_ms, exp_ms, nn_ms = mean_ms(ev_sel), mean_ms(ev_exp), mean_ms(ev_nn)
         st_all, st = st, st_probe  # byte counts must come from the same launches the events bracket
-        # algorithmic bytes: child record = Q f64 + {P f32, N i32} + meta u32 = 20 B;
+        # algorithmic bytes: child record = Q f64 + {P f32, N i32} + meta u32 = 20 B read by select,
+        # 12 B written at expansion (Q is not stored until the first visit);
         # leaf batch = packed ring 32*SW B (+ the dense planes only when a PyTorch forward consumes them)
         planes = 0.0 if run.fused is not None else nin * esize
         sel_bytes = (20.0 * st["sum_children"] + 4.0 * st["sum_depth"] + st["evals"] * (32.0 * d.state_words + planes)
                      + st["sims"] * (16.0 + 36.0 * d.state_words + 16.0)) / launches
-        exp_bytes = (st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 20.0 * st["expanded_edges"]
+        exp_bytes = (st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 12.0 * st["expanded_edges"]
                      + 32.0 * st["sum_depth"] + 36.0 * st["sims"]) / launches
         dom = ("k_select_gather", sel_bytes, sel_ms) if sel_ms >= exp_ms else ("k_expand_backup", exp_bytes, exp_ms)
 
