@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel-time profile + PMC HBM traffic of the default bench command, on the GPU box:
+# Kernel-time profile (the default bench command, minus the CPU baseline's worker processes) + PMC HBM traffic, on the GPU box:
 #   gpurun -- bash scripts/profile.sh TAG      -> gpurun_out/prof_TAG/ (kernel stats), gpurun_out/pmc_TAG/ (traffic)
 set -e -o pipefail
 TAG=${1:-r01}
@@ -7,6 +7,6 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o bench -- \
-  python3 $ROOT/bench.py --steps 1 --warmup 0 --preroll 0 --no-cpu-baseline > $ROOT/gpurun_out/prof_$TAG.log 2>&1
+  python3 $ROOT/bench.py --no-cpu-baseline > $ROOT/gpurun_out/prof_$TAG.log 2>&1
 echo "kernel trace done"
 cd $ROOT && bash scripts/pmc_traffic.sh $TAG
