@@ -134,3 +134,57 @@ def test_weight_publish_world_size_2_gloo(tmp_path):
     script.write_text(_WORKER)
     procs = [subprocess.Popen([sys.executable, str(script), str(r), str(port), ROOT]) for r in range(2)]
     assert [p.wait(timeout=120) for p in procs] == [0, 0]
+
+
+_DP_WORKER = r"""
+import sys, torch, torch.distributed as dist
+rank, port, root = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+sys.path.insert(0, root)
+from alphazero_amd.learner import DataParallelLearner, calculate_loss
+from alphazero_amd.nets import TicTacToeNet
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+torch.manual_seed(0)
+model = TicTacToeNet()
+ref = TicTacToeNet(); ref.load_state_dict(model.state_dict())
+g = torch.Generator().manual_seed(7)
+batches = []
+for r in range(2):  # both ranks know both batches: rank r trains on batch r, the check needs both
+    s = torch.randint(-1, 2, (16, 9, 3, 3), generator=g).float()
+    p = torch.softmax(torch.randn(16, 9, generator=g), 1)
+    z = torch.randint(-1, 2, (16, 1), generator=g).float()
+    batches.append((s, p, z))
+class Pool:
+    def sample(self, n, timeout=None):
+        return batches[rank]
+opt = torch.optim.SGD(model.parameters(), lr=0.1)
+dp = DataParallelLearner(model, opt, bucket_bytes=64 << 10)  # small buckets: several collectives, launched from hooks
+assert len(dp.buckets) > 1
+dp.step(Pool(), 16)
+# what it must equal: the same step with the mean of the two ranks' gradients, computed here without any collective
+grads = []
+for r in range(2):
+    m = TicTacToeNet(); m.load_state_dict(ref.state_dict()); m.train()
+    loss, _, _ = calculate_loss(m, *batches[r]); loss.backward()
+    grads.append([q.grad.clone() for q in m.parameters()])
+ok = True
+for q, ga, gb, cur in zip(ref.parameters(), grads[0], grads[1], model.parameters()):
+    want = q.detach() - 0.1 * (ga + gb) / 2
+    ok = ok and torch.allclose(cur.detach(), want, rtol=1e-5, atol=1e-6)
+# and both ranks now hold the same weights
+flat = torch.cat([q.detach().reshape(-1) for q in model.parameters()])
+other = [torch.empty_like(flat) for _ in range(2)]
+dist.all_gather(other, flat)
+ok = ok and torch.equal(other[0], other[1])
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+"""
+
+
+def test_data_parallel_learner_world_size_2_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "dp.py"
+    script.write_text(_DP_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(port), ROOT]) for r in range(2)]
+    assert [p.wait(timeout=180) for p in procs] == [0, 0]
