@@ -64,7 +64,8 @@ struct Geo {
   static_assert(NPT == 2 || NPT == 4, "conv_layer counts its fragment reads for 2 or 4 cell tiles per wave");
   static_assert(RGW * 4 <= 64 * 16, "one 16-byte LDS-DMA per lane moves the packed input");
   static size_t lds_bytes(int n_layers) {
-    return (size_t)ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + (size_t)(1 + n_layers) * CH * 4;
+    (void)n_layers;  // any depth: the bias table is a three-layer ring
+    return (size_t)ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + 3 * CH * 4;
   }
 };
 
@@ -289,12 +290,12 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   char *wbuf = smem + Q::ACT_BYTES;
   float *hw = (float *)(wbuf + 2 * STAGE_BYTES);  // 3*64 + 3 floats
   char *rgb = wbuf + 2 * STAGE_BYTES + HW_BYTES;  // 2 x {RGW ring words, BPW player words}
-  float *bl = (float *)(rgb + 2 * RG_STRIDE);     // (1+L)*64 biases
+  float *bl = (float *)(rgb + 2 * RG_STRIDE);     // 3 x 64 biases: the running layer's, the next one's (DMA'd under this layer's conv), the last one's
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   for (int i = tid; i < Q::ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero slot
   for (int i = tid; i < 3 * CH + 3; i += 256) hw[i] = i < 3 * CH ? headw[i] : headb[i - 3 * CH];
-  for (int i = tid; i < (1 + L) * CH; i += 256) bl[i] = bias[i];
+  for (int i = tid; i < CH; i += 256) bl[i] = bias[i];  // the stem's; every later layer's row arrives by LDS-DMA, one layer ahead
 
   // this lane's NPT cells (B-operand column / accumulator column): tile = NPT*wave + pt
   int pp[NPT];
@@ -344,7 +345,12 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
       glds16((const char *)ring + (size_t)dma_slot * BOARD_BYTES + (lane * 16) % BOARD_BYTES, dst);
     if (lane < BPW && mine >= 0) glds4(&leafrec[mine].w, dst + RGW * 4);
   };
-  int buf = 0, inb = 0, it = 0;
+  int buf = 0, inb = 0, it = 0, bslot = 0;
+  // bias row of `layer` -> the ring slot after the running one (wave 0; lands before the running conv's first stage barrier)
+  auto bias_ahead = [&](int layer) {
+    if (wave == 0) glds4(bias + layer * CH + lane, (char *)(bl + (bslot == 2 ? 0 : bslot + 1) * CH));
+  };
+  auto bias_step = [&]() { bslot = bslot == 2 ? 0 : bslot + 1; };
   if (blockIdx.x < ngroups) {  // prologue: the stem's first weight stage and the first group's input
     stage_w<1, ST>(w0, wbuf, wave, lane);
     stage_input(0, 0);
@@ -398,10 +404,13 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     f32x16 acc[NPT][2];
     uint2 res[NPT][2][4];
     // ---- stem
-    init_acc<false, NPT>(bl, lane, acc, res);
+    init_acc<false, NPT>(bl + bslot * CH, lane, acc, res);
+    if (L > 0) bias_ahead(1);
+    else if (has_next) bias_ahead(0);
     if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
     else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, has_next ? w0 : nullptr, tid, lane, pp, vm, acc);
     STAMP(2);
+    bias_step();
     epilogue<NPT>(act, lane, pp, ok, acc);
     __syncthreads();
     STAMP(3);
@@ -422,15 +431,19 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
 #else
       unsigned long long *twp = nullptr;
 #endif
-      init_acc<false, NPT>(bl + (1 + l) * CH, lane, acc, res);
+      init_acc<false, NPT>(bl + bslot * CH, lane, acc, res);
+      bias_ahead(2 + l);
       STAMP(sk + 0);
       conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
                                        lane, pp, vm, acc, twp);
       STAMP(sk + 1);
+      bias_step();
       epilogue<NPT>(act, lane, pp, ok, acc);
       __syncthreads();
       STAMP(sk + 2);
-      init_acc<true, NPT>(bl + (2 + l) * CH, lane, acc, res);
+      init_acc<true, NPT>(bl + bslot * CH, lane, acc, res);
+      if (l + 2 < L) bias_ahead(3 + l);
+      else if (has_next) bias_ahead(0);
       STAMP(sk + 3);
       if (l + 2 < L)
         conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
@@ -439,6 +452,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
         conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, has_next ? w0 : nullptr, tid, lane,
                                          pp, vm, acc, twp);
       STAMP(sk + 4);
+      bias_step();
       epilogue<NPT>(act, lane, pp, ok, acc);
       __syncthreads();
       STAMP(sk + 5);
@@ -513,7 +527,7 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
   hipStream_t s = (hipStream_t)stream;
   hipError_t err;
   auto launch = [&](auto kern, size_t lds, int bpw) -> int {
-    if (lds > 160 * 1024) { g_tower_err = "too many layers for the LDS bias table"; return AZ_EINVAL; }
+    if (lds > 160 * 1024) { g_tower_err = "tower geometry exceeds the CU's LDS"; return AZ_EINVAL; }
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * AZ_TOWER_WAVES_PER_SIMD;
     int grid = groups < cap ? groups : cap;

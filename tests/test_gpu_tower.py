@@ -19,7 +19,8 @@ def _randomised(net):
     return net
 
 
-@pytest.mark.parametrize("board,blocks,batch", [(15, 2, 64), (15, 2, 1000), (15, 3, 33), (9, 2, 100), (9, 1, 7), (15, 0, 5)])
+@pytest.mark.parametrize("board,blocks,batch", [(15, 2, 64), (15, 2, 1000), (15, 3, 33), (9, 2, 100), (9, 1, 7), (15, 0, 5), (15, 10, 600),
+                                                (9, 6, 50)])
 def test_fused_tower_matches_fp32_forward(board, blocks, batch):
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import GomokuNet
