@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: gomoku 15x15, 800 simulations per move, a deep residual tower, self-play AND training on
+every GPU of the node (alphazero_amd.loop.SelfPlayTrainLoop).
+
+  python examples/selfplay_train.py --moves 20                                   (one GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+      examples/selfplay_train.py --moves 20                                      (one process per GPU, RCCL)
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--moves", type=int, default=10)
+    ap.add_argument("--slots", type=int, default=16384)
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--blocks", type=int, default=10)
+    ap.add_argument("--board", type=int, default=15, choices=[9, 15])
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--train-steps-per-move", type=int, default=4)
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from alphazero_amd.loop import SelfPlayTrainLoop
+    from alphazero_amd.nets import GomokuNet
+
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(1234 + rank)
+    loop = SelfPlayTrainLoop(GomokuNet(args.board, 64, args.blocks), 2, args.board, args.slots, args.sims, dev,
+                             batch_size=args.batch, train_steps_per_move=args.train_steps_per_move)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = loop.run(args.moves)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(f"{world} GPU(s): {args.moves} moves of {args.slots} games x {args.sims} sims in {dt:.1f} s = "
+              f"{world * args.moves * args.slots * args.sims / dt / 1e6:.2f} M sims/s; per rank {out}")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

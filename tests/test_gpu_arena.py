@@ -163,3 +163,35 @@ def test_gpu_worker_has_the_reference_worker_signature():
     assert len(pool.items) == 12 * 24  # every dots-and-boxes game has exactly 24 plies
     st, pi, z = pool.items[0]
     assert st.shape == (1, 25, 4, 4) and pi.shape == (1, 24) and z.shape == (1,)
+
+
+def test_self_play_train_loop_runs_and_learns():
+    """BASELINE config 5 in miniature: self-play -> device ring -> learner -> refreshed self-play net, one GPU"""
+    from alphazero_amd.loop import SelfPlayTrainLoop
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(0)
+    loop = SelfPlayTrainLoop(GomokuNet(9, 64, 1), 2, 9, 64, 8, torch.device("cuda:0"), ring_capacity=1 << 14, batch_size=128,
+                             train_steps_per_move=2, min_samples=512, publish_every=4)
+    assert loop.runner.fused is not None  # the bf16 self-play copy runs on the fused tower
+    before = {k: v.clone() for k, v in loop.player.state_dict().items()}
+    out = loop.run(60)
+    assert out["games"] > 0 and out["train_steps"] >= 20 and out["samples"] > 0 and loop.ring.size() > 0
+    changed = any(not torch.equal(before[k], v) for k, v in loop.player.state_dict().items())
+    assert changed  # the self-play network follows the learner ...
+    x = torch.randint(-1, 2, (32, 9, 9, 9), device="cuda").float()
+    with torch.inference_mode():
+        want_p, want_v = loop.master.eval()(x)
+    got_p, got_v = loop.runner.fused(x.bfloat16().contiguous())
+    scale = float(want_p.abs().max())
+    assert float((got_p - want_p).abs().max()) <= 0.03 * scale + 0.02  # ... and so does the fused tower's folded copy
+    assert float((got_v - want_v).abs().max()) <= 0.03
+
+    class Fixed:  # the learner itself: repeated steps on one batch of the loop's own samples must fit it
+        batch = loop.ring.sample(256)
+
+        def sample(self, n, timeout=None):
+            return self.batch
+
+    losses = [loop.learner.step(Fixed(), 256)[0] for _ in range(40)]
+    assert losses[-1] < 0.8 * losses[0]
