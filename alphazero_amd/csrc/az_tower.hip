@@ -106,17 +106,34 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 #define AZ_TOWER_WAVES_PER_SIMD 2
 #endif
 
-// stage ST taps of weights (ST*KS*2 KiB, [tap][ks][half][co][8] bf16) into an LDS buffer:
-// 1 KiB per wave-instruction, chunks dealt round-robin to the 4 waves
+// async global -> LDS copy of 16 B per lane with an immediate byte offset applied to BOTH addresses
+template <int OFF>
+__device__ __forceinline__ void glds16o(const char *g_lane, char *lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
+                                   (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)lds_base, 16, OFF, 0);
+}
+
+// stage ST taps of weights (NCHUNK = ST*KS*2 KiB, [tap][ks][half][co][8] bf16, contiguous in global memory and in the
+// LDS buffer alike): 1 KiB per wave-instruction, each wave a run of consecutive pieces, four pieces per address
+// pair through the instruction's immediate offset -- a handful of instructions per stage, issued under the MFMAs
 template <int KS, int ST>
 __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave, int lane) {
-  constexpr int NCHUNK = ST * KS * 2;
+  constexpr int NCHUNK = ST * KS * 2, PW = (NCHUNK + 3) / 4;
 #if AZ_TOWER_ABLATE == 3  // diagnostic build: no weight streaming at all
   return;
 #endif
+  const int first = wave * PW;  // wave-uniform
+  const char *g = wg_src + first * 1024 + lane * 16;
+  char *l = dst + first * 1024;
 #pragma unroll
-  for (int c = 0; c < NCHUNK; c += 4)
-    if (c + wave < NCHUNK) glds16(wg_src + (c + wave) * 1024 + lane * 16, dst + (c + wave) * 1024);
+  for (int p = 0; p < PW; p += 4) {
+    const char *gp = g + p * 1024;
+    char *lp = l + p * 1024;
+    if (first + p + 0 < NCHUNK) glds16o<0>(gp, lp);
+    if (p + 1 < PW && first + p + 1 < NCHUNK) glds16o<1024>(gp, lp);
+    if (p + 2 < PW && first + p + 2 < NCHUNK) glds16o<2048>(gp, lp);
+    if (p + 3 < PW && first + p + 3 < NCHUNK) glds16o<3072>(gp, lp);
+  }
 }
 
 // one conv layer, in registers: acc[pt][ct] += W * X.  KS = 16-channel k-steps per tap (1 or 4).
@@ -125,24 +142,25 @@ __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave,
 // layer is already in buffer `buf` (landed and barriered); during the last stage the first stage of the NEXT
 // layer (wnext, KSN k-steps per tap; nullptr = none) is prefetched, so no layer starts with an exposed DMA.
 // The k-steps of a stage are software pipelined through two register sets: the four fragment reads of step
-// i+1 are issued before the four MFMAs of step i.  A lane's B address for a tap is ONE base (the 128-byte row of
-// the shifted cell with the swizzle of its first chunk folded in, or the 128-byte zero row when the tap is off
-// the board); the k-step then only XORs (ks << 5) into it.
+// i+1 are issued before the four MFMAs of step i; the next stage's DMA is issued after the stage's first MFMAs
+// (under them, not before them), and the activation fragments of the NEXT stage's first k-step are requested
+// before the stage barrier (the layer's input does not change while the layer runs), so a wave comes out of the
+// barrier with half of its operands already on the way.  A lane's B address for a tap is ONE base (the 128-byte
+// row of the shifted cell with the swizzle of its first chunk folded in, or the 128-byte zero row when the tap is
+// off the board); the k-step then only XORs (ks << 5) into it.
+// Fragment reads are inline asm with hand-counted waits: hipcc's own ds_read + MFMA schedule here reads each
+// fragment just before its MFMA and waits lgkmcnt(0) every time (one exposed LDS round trip per two MFMAs).
 template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST>
 __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext,
                                            int tid, int lane, const int (&pp)[NPT], const uint32_t (&vm)[NPT],
                                            f32x16 (&acc)[NPT][2], unsigned long long *twait = nullptr) {
   constexpr int TB = KS * 2048;  // bytes per tap
   constexpr int NSTAGE = 9 / ST, STAGE_BYTES = ST * TAP_BYTES, NK = ST * KS;
+  constexpr bool XPF = (NK % 2 == 0) && NSTAGE > 1;  // cross-barrier prefetch needs the last k-step in register set 1
   const int h = lane >> 5, r = lane & 31, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll 1
-  for (int sg = 0; sg < NSTAGE; ++sg) {
-    // the DMA of the next stage's weights runs under this stage's MFMAs
-    char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
-    if (sg < NSTAGE - 1) stage_w<KS, ST>(wg + (sg + 1) * ST * TB, wn, wave, lane);
-    else if (wnext != nullptr) stage_w<KSN, ST>(wnext, wn, wave, lane);
-    const char *wa = wbuf + ((buf + sg) & 1) * STAGE_BYTES + h * 1024 + r * 16;
-    uint32_t bb[ST][NPT];
+  const uint32_t act32 = (uint32_t)(uintptr_t)act;
+  uint32_t bb[ST][NPT];
+  auto bases = [&](int sg) {
 #pragma unroll
     for (int j = 0; j < ST; ++j) {
       const int tap = sg * ST + j;
@@ -154,56 +172,78 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
         bb[j][pt] = ((vm[pt] >> tap) & 1u) ? in : (uint32_t)(ZERO_OFF | (h << 4));
       }
     }
-    // Fragment reads are inline asm with hand-counted waits: hipcc's own ds_read + MFMA schedule here reads each
-    // fragment just before its MFMA and waits lgkmcnt(0) every time (one exposed LDS round trip per two MFMAs).
-    constexpr int PD = AZ_TOWER_PREFETCH < NK ? AZ_TOWER_PREFETCH : NK - 1;  // k-steps of fragments in flight ahead of the MFMAs
-    constexpr int NS = PD + 1;
-    bf16x8 fa[NS][2], fb[NS][NPT];
-    const uint32_t wa32 = (uint32_t)(uintptr_t)wa, act32 = (uint32_t)(uintptr_t)act;
-    auto load = [&](int i, int s) {
+  };
+  bf16x8 fa[2][2], fb[2][NPT];
+  auto load_b = [&](int i, int s) {
+    const int j = i / KS, ks = i % KS;
+#if AZ_TOWER_ABLATE == 2 || AZ_TOWER_ABLATE == 4
+    if (i < 2) for (int pt = 0; pt < NPT; ++pt) fb[s][pt] = (bf16x8)(__bf16)(AZ_TOWER_ABLATE == 2 ? (float)bb[j][pt] : 0.0f);
+    return;
+#endif
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt)
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][pt]) : "v"(act32 + (bb[j][pt] ^ (uint32_t)(ks << 5))));
+  };
+  bases(0);
+  if (XPF) load_b(0, 0);
+#pragma unroll 1
+  for (int sg = 0; sg < NSTAGE; ++sg) {
+    const uint32_t wa32 = (uint32_t)(uintptr_t)(wbuf + ((buf + sg) & 1) * STAGE_BYTES + h * 1024 + r * 16);
+    auto load_a = [&](int i, int s) {
       const int j = i / KS, ks = i % KS;
-#if AZ_TOWER_ABLATE == 2  // diagnostic build: MFMAs on register operands, no LDS fragment reads
-      if (i < NS) { fa[s][0] = fa[s][1] = (bf16x8)(__bf16)1.0f; for (int pt = 0; pt < NPT; ++pt) fb[s][pt] = (bf16x8)(__bf16)(float)bb[j][pt]; }
+#if AZ_TOWER_ABLATE == 2 || AZ_TOWER_ABLATE == 4
+      if (i < 2) fa[s][0] = fa[s][1] = (bf16x8)(__bf16)(AZ_TOWER_ABLATE == 2 ? 1.0f : 0.0f);
       return;
 #endif
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][0]) : "v"(wa32), "i"(j * TB + ks * 2048));
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][1]) : "v"(wa32), "i"(j * TB + ks * 2048 + 512));
-#pragma unroll
-      for (int pt = 0; pt < NPT; ++pt)
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][pt]) : "v"(act32 + (bb[j][pt] ^ (uint32_t)(ks << 5))));
     };
-#pragma unroll
-    for (int i = 0; i < PD; ++i) load(i, i);
+    if (!XPF) { if (sg > 0) bases(sg); load_b(0, 0); }
+    load_a(0, 0);
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
-      if (i + PD < NK) load(i + PD, (i + PD) % NS);
-      {  // wait until step i's 2 + NPT reads have returned: everything issued after them may still be in flight
-        constexpr int RPS = 2 + NPT;
-        const int ahead = (NK - 1 - i < PD ? NK - 1 - i : PD) * RPS;
-        if (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else if (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        else if (ahead == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        else if (ahead == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        else if (ahead == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (i + 1 < NK) {
+        load_a(i + 1, (i + 1) & 1);
+        load_b(i + 1, (i + 1) & 1);
+        if (NPT == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // step i's reads have returned
+        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      } else if (XPF && sg + 1 < NSTAGE) {
+        bases(sg + 1);  // the next stage's first activation fragments: in flight across the stage barrier
+        load_b(0, 0);
+        if (NPT == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pt = 0; pt < NPT; ++pt) {
 #if AZ_TOWER_ABLATE == 1  // diagnostic build: LDS fragment reads kept alive, no MFMAs
-        asm volatile("" ::"v"(fa[i % NS][0]), "v"(fa[i % NS][1]), "v"(fb[i % NS][pt]));
+        asm volatile("" ::"v"(fa[i & 1][0]), "v"(fa[i & 1][1]), "v"(fb[i & 1][pt]));
 #else
-        acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % NS][0], fb[i % NS][pt], acc[pt][0], 0, 0, 0);
-        acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % NS][1], fb[i % NS][pt], acc[pt][1], 0, 0, 0);
+        acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][0], fb[i & 1][pt], acc[pt][0], 0, 0, 0);
+        acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][1], fb[i & 1][pt], acc[pt][1], 0, 0, 0);
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (i == 0) {  // the DMA of the next stage's weights: issued under this stage's MFMAs
+        char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
+        if (sg < NSTAGE - 1) stage_w<KS, ST>(wg + (sg + 1) * ST * TB, wn, wave, lane);
+        else if (wnext != nullptr) stage_w<KSN, ST>(wnext, wn, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #if AZ_TOWER_STAMP
     const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next stage has landed
-    __syncthreads();  // after the last stage: every wave has finished reading act -> the epilogue may overwrite it
+    if (XPF && sg + 1 < NSTAGE) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // compiler-level ordering only matters for the DMA'd bytes:
+      __builtin_amdgcn_s_barrier();                            // a raw barrier, so the prefetched reads stay in flight
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+      __syncthreads();  // after the last stage: every wave has finished reading act -> the epilogue may overwrite it
+    }
 #if AZ_TOWER_STAMP
     if (twait) *twait += __builtin_amdgcn_s_memtime() - tw0;
 #endif
