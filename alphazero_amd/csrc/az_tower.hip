@@ -59,7 +59,7 @@ struct Geo {
   static constexpr int ACT_BYTES = NVT * 128 + 128;
   static constexpr int STAGE_BYTES = ST * TAP_BYTES;
   static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = BPW * 8 * SWB;  // packed input words per group
-  static constexpr int RG_BYTES = ((RGW * 4 + 8 * BPW + 15) / 16) * 16;         // ring words, BPW players, BPW slots
+  static constexpr int RG_BYTES = ((RGW * 4 + 8 * BPW + 4 + 15) / 16) * 16;     // ring words, BPW players, BPW slots, the group's ticket
   static_assert(NVT <= 4 * NPT * 32, "4 waves x NPT tiles of 32 cells");
   static_assert(NPT == 2 || NPT == 4, "conv_layer counts its fragment reads for 2 or 4 cell tiles per wave");
   static_assert(RGW * 4 <= 64 * 16, "one 16-byte LDS-DMA per lane moves the packed input");
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
                                                const int32_t *__restrict__ count, int G, const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
-                                               float *__restrict__ pfeat, float *__restrict__ vfeat) {
+                                               float *__restrict__ pfeat, float *__restrict__ vfeat, unsigned int *tickets) {
   using Q = Geo<N, BPW, NPT, ST>;
   constexpr int WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RG_STRIDE = Q::RG_BYTES, STAGE_BYTES = Q::STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -360,30 +360,38 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   const int nb_total = (list != nullptr && count != nullptr) ? min(*count, G) : G;
   const int ngroups = (nb_total + BPW - 1) / BPW;
   constexpr int BOARD_BYTES = 8 * SWB * 4;
-  // wave 0, lane k keeps the slots of this workgroup's k-th group (<= 64 groups per workgroup, see the host side)
-  int sl[BPW];
-#pragma unroll
-  for (int b = 0; b < BPW; ++b) {
-    const int ci = (blockIdx.x + lane * (int)gridDim.x) * BPW + b;
-    sl[b] = (wave == 0 && ci < nb_total) ? (list != nullptr ? list[ci] : ci) : -1;
-  }
-  // stage the `it`-th group's input into buffer `which` (wave 0): slots by ds_write, ring words + players by LDS-DMA
-  auto stage_input = [&](int it, int which) {
+  // Groups of BPW boards are handed out by a ticket counter, not by block index: the two workgroups that share a CU
+  // do not run at the same speed (the MFMA pipe favours the older one's waves: measured 818 vs 1,008 us for 32 boards
+  // each), so a fixed split leaves every CU half empty for the last fifth of the launch.  tickets[0] = next group,
+  // tickets[1] = workgroups that have drawn a ticket past the end; the last of them zeroes both for the next launch.
+  // Wave 0 runs the protocol one group ahead, in three steps spread over the current group's tower so that none of
+  // them is waited for: draw (atomic), look the slots up in the list, start the DMA of the packed input.
+  int tk_draw = 0, tk_next = 0, sl_next = -1;  // wave 0: the next group's ticket; lane b < BPW: its b-th slot
+  auto draw = [&]() {  // step 1: lane 0's returning atomic; nothing reads the result before step 2
+    if (wave == 0 && lane == 0) tk_draw = (int)atomicAdd(&tickets[0], 1u);
+  };
+  auto lookup = [&]() {  // step 2 (uses the ticket)
+    if (wave != 0) return;
+    tk_next = __builtin_amdgcn_readfirstlane(tk_draw);
+    const int ci = tk_next * BPW + lane;
+    sl_next = (tk_next < ngroups && lane < BPW && ci < nb_total) ? (list != nullptr ? list[ci] : ci) : -1;
+  };
+  auto fetch = [&](int which) {  // step 3 (uses the slots): slots + ticket by ds_write, ring words + players by LDS-DMA
     if (wave != 0) return;
     char *dst = rgb + which * RG_STRIDE;
-    int mine = -1, dma_slot = -1;
+    int dma_slot = -1;
     const int db = (lane * 16) / BOARD_BYTES;  // the board this lane's 16-byte DMA piece belongs to
 #pragma unroll
     for (int b = 0; b < BPW; ++b) {
-      const int sb = __shfl(sl[b], it, 64);
-      if (lane == b) mine = sb;
+      const int sb = __shfl(sl_next, b, 64);
       if (db == b) dma_slot = sb;
     }
-    if (lane < BPW) ((int *)dst)[RGW + BPW + lane] = mine;
+    if (lane < BPW) ((int *)dst)[RGW + BPW + lane] = sl_next;
+    if (lane == 0) ((int *)dst)[RGW + 2 * BPW] = tk_next;
     if (x != nullptr) return;
     if (lane * 16 < BPW * BOARD_BYTES && dma_slot >= 0)
       glds16((const char *)ring + (size_t)dma_slot * BOARD_BYTES + (lane * 16) % BOARD_BYTES, dst);
-    if (lane < BPW && mine >= 0) glds4(&leafrec[mine].w, dst + RGW * 4);
+    if (lane < BPW && sl_next >= 0) glds4(&leafrec[sl_next].w, dst + RGW * 4);
   };
   int buf = 0, inb = 0, it = 0, bslot = 0;
   // bias row of `layer` -> the ring slot after the running one (wave 0; lands before the running conv's first stage barrier)
@@ -391,29 +399,35 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     if (wave == 0) glds4(bias + layer * CH + lane, (char *)(bl + (bslot == 2 ? 0 : bslot + 1) * CH));
   };
   auto bias_step = [&]() { bslot = bslot == 2 ? 0 : bslot + 1; };
-  if (blockIdx.x < ngroups) {  // prologue: the stem's first weight stage and the first group's input
-    stage_w<1, ST>(w0, wbuf, wave, lane);
-    stage_input(0, 0);
-  }
+  // prologue: the stem's first weight stage and the first group's input
+  stage_w<1, ST>(w0, wbuf, wave, lane);
+  draw();
+  lookup();
+  fetch(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
 #if AZ_TOWER_STAMP
   unsigned long long tsv[32];
   for (int k = 0; k < 32; ++k) tsv[k] = 0;
+  tsv[20] = __builtin_amdgcn_s_memtime();
+  tsv[21] = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x, ++it) {
-    const bool has_next = grp + (int)gridDim.x < ngroups;
+  for (;; ++it) {
+    const uint32_t *rg = (const uint32_t *)(rgb + inb * RG_STRIDE);
+    const int *slots = (const int *)rg + RGW + BPW;
+    if (slots[BPW] >= ngroups) break;  // this workgroup's ticket is past the end (the same word for every thread)
 #if AZ_TOWER_STAMP
     const bool stamp_on = blockIdx.x == 7 && it == 5;
     unsigned long long tw = 0;
 #endif
     STAMP(0);
-    if (has_next) stage_input(it + 1, inb ^ 1);  // lands under this group's tower
+#if AZ_TOWER_STAMP
+    if (stamp_on) tsv[30] = __builtin_amdgcn_s_memrealtime();
+#endif
+    draw();  // the next group's ticket: on its way while this group's input is expanded and the stem runs
     // ---- input -> act[cell][0..15] (channels 9..15 zero): the NCHW bf16 planes, or the packed leaf batch
     // (8 bitboard states per board + the player to move), expanded here
-    const uint32_t *rg = (const uint32_t *)(rgb + inb * RG_STRIDE);
-    const int *slots = (const int *)rg + RGW + BPW;
     for (int m = fresh(tid); m < Q::NVT; m += 256) {
       const int b = m / Q::NV, cell = m % Q::NV, g = slots[b];
       uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -446,14 +460,16 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     // ---- stem
     init_acc<false, NPT>(bl + bslot * CH, lane, acc, res);
     if (L > 0) bias_ahead(1);
-    else if (has_next) bias_ahead(0);
+    else bias_ahead(0);  // (the next group's stem; harmless when there is none)
     if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
-    else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, has_next ? w0 : nullptr, tid, lane, pp, vm, acc);
+    else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, w0, tid, lane, pp, vm, acc);
     STAMP(2);
     bias_step();
     epilogue<NPT>(act, lane, pp, ok, acc);
     __syncthreads();
     STAMP(3);
+    lookup();  // the ticket drawn at the top of the loop has long arrived
+    if (L == 0) fetch(inb);
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
       const int h = fresh(lane) >> 5;
@@ -481,15 +497,16 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
       epilogue<NPT>(act, lane, pp, ok, acc);
       __syncthreads();
       STAMP(sk + 2);
+      if (l == 0) fetch(inb);  // the next group's packed input: lands under the rest of this group's tower
       init_acc<true, NPT>(bl + bslot * CH, lane, acc, res);
       if (l + 2 < L) bias_ahead(3 + l);
-      else if (has_next) bias_ahead(0);
+      else bias_ahead(0);
       STAMP(sk + 3);
       if (l + 2 < L)
         conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
                                          tid, lane, pp, vm, acc, twp);
       else  // last layer of this board: prefetch the next board's stem weights
-        conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, has_next ? w0 : nullptr, tid, lane,
+        conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, w0, tid, lane,
                                          pp, vm, acc, twp);
       STAMP(sk + 4);
       bias_step();
@@ -542,15 +559,40 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     __syncthreads();  // heads done reading before the next group's input overwrites act
     STAMP(29);
 #if AZ_TOWER_STAMP
-    if (stamp_on && lane == 0)
-      for (int k = 0; k < 32; ++k) ((unsigned long long *)vfeat)[wave * 32 + k] = tsv[k];
+    if (stamp_on) tsv[31] = __builtin_amdgcn_s_memrealtime();
 #endif
   }
+  // past the end: report in; the last workgroup to do so re-arms the counters for the next launch
+  if (tid == 0 && atomicAdd(&tickets[1], 1u) == gridDim.x - 1) {
+    tickets[0] = 0u;
+    tickets[1] = 0u;
+    __threadfence();
+  }
+#if AZ_TOWER_STAMP
+  if (tid == 0) {  // every workgroup: start / end on the global 100 MHz counter, behind the per-wave rows
+    unsigned long long *o = (unsigned long long *)vfeat + 4 * 32 + 4 * blockIdx.x;
+    o[0] = tsv[21]; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = it; o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4) << 8);  // XCC_ID | HW_ID << 8
+  }
+  if (blockIdx.x == 7 && lane == 0) {  // whole-kernel stamps of one workgroup
+    tsv[22] = __builtin_amdgcn_s_memtime();
+    tsv[23] = __builtin_amdgcn_s_memrealtime();
+    tsv[24] = it;
+    for (int k = 0; k < 32; ++k) ((unsigned long long *)vfeat)[wave * 32 + k] = tsv[k];
+  }
+#endif
 }
 
 }  // namespace aztower
 
 static std::string g_tower_err;
+
+// Ticket counters of the tower launches: {next group, workgroups done} pairs, zero at load and re-armed by each launch's
+// last workgroup.  Launches rotate through 16 pairs, so up to 16 launches may be in flight on one GPU (e.g. two
+// engines on two streams).  A __device__ array exists once per GPU; its address is looked up per device.
+#define AZ_TOWER_TICKET_PAIRS 16
+static __device__ unsigned int g_tower_tickets[2 * AZ_TOWER_TICKET_PAIRS];
+static unsigned int *g_ticket_base[64];
+static unsigned int g_ticket_seq[64];
 
 extern "C" {
 
@@ -566,17 +608,27 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
   if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1)) { g_tower_err = "n_boards >= 1, even n_conv_layers"; return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   hipError_t err;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { g_tower_err = "hipGetDevice failed"; return AZ_EHIP; }
+  if (g_ticket_base[dev] == nullptr) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tower_tickets)) != hipSuccess || p == nullptr) {
+      g_tower_err = "hipGetSymbolAddress(g_tower_tickets) failed";
+      return AZ_EHIP;
+    }
+    g_ticket_base[dev] = (unsigned int *)p;
+  }
+  unsigned int *tickets = g_ticket_base[dev] + 2 * (g_ticket_seq[dev]++ % AZ_TOWER_TICKET_PAIRS);
   auto launch = [&](auto kern, size_t lds, int bpw) -> int {
     if (lds > 160 * 1024) { g_tower_err = "tower geometry exceeds the CU's LDS"; return AZ_EINVAL; }
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * AZ_TOWER_WAVES_PER_SIMD;
-    int grid = groups < cap ? groups : cap;
-    if ((groups + grid - 1) / grid > 64) grid = (groups + 63) / 64;  // a workgroup keeps <= 64 groups' slots in one wave
+    const int grid = groups < cap ? groups : cap;
     const bool use_list = !x_bf16_dev && list_dev && count_dev;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
                        (const int4 *)packed_leaf_dev, (const int32_t *)(use_list ? list_dev : nullptr),
                        (const int32_t *)(use_list ? count_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
-                       n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev);
+                       n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev, tickets);
     return AZ_OK;
   };
   int rc;
