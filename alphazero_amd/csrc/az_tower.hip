@@ -315,14 +315,14 @@ __device__ __forceinline__ void glds4(const void *g_lane, void *lds_base) {
 // x: (G, 9, N, N) bf16, or nullptr to read the engine's packed leaf batch (ring u32 (G,8,SWB) + leaf records).
 // w0: [9][1][2][64][8] bf16 (first conv, 9 input channels padded to 16).  wl: [L][9][4][2][64][8] bf16.
 // bias: [1+L][64] f32.  headw: [3][64] f32 (policy, value0, value1), headb: [3].
-// pfeat: (G, NV) f32, vfeat: (G, 2, NV) f32 (= the inputs of the heads' Linear layers).
+// feat: (G, FS) bf16 = the inputs of the heads' Linear layers (layout: see the heads' epilogue and k_heads).
 template <int N, int BPW, int NPT, int ST>
 __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
                                                const int4 *__restrict__ leafrec, const int32_t *__restrict__ list,
                                                const int32_t *__restrict__ count, int G, const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
-                                               float *__restrict__ pfeat, float *__restrict__ vfeat, unsigned int *tickets) {
+                                               uint16_t *__restrict__ feat, int FS, unsigned int *tickets) {
   using Q = Geo<N, BPW, NPT, ST>;
   constexpr int WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RG_STRIDE = Q::RG_BYTES, STAGE_BYTES = Q::STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -549,9 +549,12 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
           if (!ok[pt]) continue;
           const int m = fresh(pp[pt]), b = m / Q::NV, cell = m % Q::NV, g = slots[b];
           if (g < 0) continue;
-          pfeat[(size_t)g * Q::NV + cell] = fmaxf(hacc[pt][0] + hw[3 * CH + 0], 0.0f);
-          vfeat[((size_t)g * 2 + 0) * Q::NV + cell] = fmaxf(hacc[pt][1] + hw[3 * CH + 1], 0.0f);
-          vfeat[((size_t)g * 2 + 1) * Q::NV + cell] = fmaxf(hacc[pt][2] + hw[3 * CH + 2], 0.0f);
+          // the heads' Linear inputs, bf16: [policy NV | pad to 16 | value0 NV | value1 NV | pad] (az_heads_forward reads it)
+          constexpr int KP = (Q::NV + 15) / 16 * 16;
+          uint16_t *fr = feat + (size_t)g * FS;
+          fr[cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(hacc[pt][0] + hw[3 * CH + 0], 0.0f));
+          fr[KP + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(hacc[pt][1] + hw[3 * CH + 1], 0.0f));
+          fr[KP + Q::NV + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(hacc[pt][2] + hw[3 * CH + 2], 0.0f));
         }
       }
     }
@@ -570,16 +573,100 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   }
 #if AZ_TOWER_STAMP
   if (tid == 0) {  // every workgroup: start / end on the global 100 MHz counter, behind the per-wave rows
-    unsigned long long *o = (unsigned long long *)vfeat + 4 * 32 + 4 * blockIdx.x;
+    unsigned long long *o = (unsigned long long *)feat + 4 * 32 + 4 * blockIdx.x;
     o[0] = tsv[21]; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = it; o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4) << 8);  // XCC_ID | HW_ID << 8
   }
   if (blockIdx.x == 7 && lane == 0) {  // whole-kernel stamps of one workgroup
     tsv[22] = __builtin_amdgcn_s_memtime();
     tsv[23] = __builtin_amdgcn_s_memrealtime();
     tsv[24] = it;
-    for (int k = 0; k < 32; ++k) ((unsigned long long *)vfeat)[wave * 32 + k] = tsv[k];
+    for (int k = 0; k < 32; ++k) ((unsigned long long *)feat)[wave * 32 + k] = tsv[k];
   }
 #endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The heads' Linear layers (examples/gomoku/model.py:69-90: policy Linear(NV -> NV); value Linear(2 NV -> 64), ReLU,
+// Linear(64 -> 1), tanh) for a whole batch, as two small bf16 MFMA GEMMs read straight from L2 (no LDS staging: the
+// feature rows and the fragment-packed weights are read once per wave, the kernel is one round of 4-wave workgroups).
+// One workgroup = 32 boards.  D[board][n] = sum_k feat[board][k] * W[n][k]: A = features (lane: board l&31, k-half l>>5),
+// B = weights (lane: output n = l&31), so a register of the result is 32 consecutive outputs of one board (coalesced).
+//   policy: wave w computes output tiles w, w+4, ... over K = KP;
+//   value:  wave w computes hidden tile w&1 over K-half w>>1 of KV; halves are summed through LDS, then
+//           v = tanh(sum_n relu(hid[n] + b1[n]) * w2[n] + b2) by a lane butterfly.
+// feat (G, FS) bf16: [0, KP) policy features (NV real), [KP, KP + KV) value features (2 NV real); pads are zero.
+// wp: [NTP][KSP][2][32][8] bf16, w1: [2][KSV][2][32][8] bf16 ([n-tile][k-step][k-half][n][8 k]), zero padded.
+template <int NV>
+__global__ __launch_bounds__(256, 2) void k_heads(const uint16_t *__restrict__ feat, int FS, int G, const char *__restrict__ wp,
+                                                  const float *__restrict__ bp, const char *__restrict__ w1,
+                                                  const float *__restrict__ b1, const float *__restrict__ w2, float b2,
+                                                  float *__restrict__ logits, float *__restrict__ values) {
+  constexpr int KP = (NV + 15) / 16 * 16, KSP = KP / 16, NTP = (NV + 31) / 32;
+  constexpr int KV = (2 * NV + 15) / 16 * 16, KSV = KV / 16, KH = (KSV + 1) / 2;
+  __shared__ float part[4][32][33];
+  __shared__ float vsum[2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int g0 = blockIdx.x * 32;
+  const int gr = min(g0 + r, G - 1);  // rows past the batch are computed on a copy of the last row and not stored
+  const uint16_t *fa = feat + (size_t)gr * FS + 8 * h;
+  // ---- policy
+  for (int nt = wave; nt < NTP; nt += 4) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const char *wb = wp + ((size_t)nt * KSP * 2 + h) * 512 + r * 16;
+#pragma unroll
+    for (int ks = 0; ks < KSP; ++ks) {
+      const bf16x8 a = *(const bf16x8 *)(fa + ks * 16);
+      const bf16x8 b = *(const bf16x8 *)(wb + (size_t)ks * 1024);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    const int n = nt * 32 + r;
+    const float bias = n < NV ? bp[n] : 0.0f;
+    if (n < NV) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (g0 + row < G) logits[(size_t)(g0 + row) * NV + n] = acc[i] + bias;
+      }
+    }
+  }
+  // ---- value: hidden tile (wave & 1), K half (wave >> 1)
+  {
+    const int nt = wave & 1, kh = wave >> 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const char *wb = w1 + ((size_t)nt * KSV * 2 + h) * 512 + r * 16;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int ks = kh * KH + k;
+      if (ks < KSV) {
+        const bf16x8 a = *(const bf16x8 *)(fa + KP + ks * 16);
+        const bf16x8 b = *(const bf16x8 *)(wb + (size_t)ks * 1024);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i];
+    __syncthreads();
+    if (wave < 2) {
+      const int n = wave * 32 + r;
+      const float bn = b1[n], wn = w2[n];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        float t = fmaxf(part[wave][row][r] + part[wave + 2][row][r] + bn, 0.0f) * wn;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (r == 0) vsum[wave][row] = t;
+      }
+    }
+    __syncthreads();
+    if (tid < 32 && g0 + tid < G) values[g0 + tid] = tanhf(vsum[0][tid] + vsum[1][tid] + b2);
+  }
 }
 
 }  // namespace aztower
@@ -598,14 +685,40 @@ extern "C" {
 
 const char *az_tower_last_error(void) { return g_tower_err.c_str(); }
 
+int32_t az_heads_feat_stride(int32_t board_size) {
+  const int nv = board_size * board_size;
+  return (nv + 15) / 16 * 16 + (2 * nv + 15) / 16 * 16;
+}
+
+int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16_dev, int32_t feat_stride, const void *wp_dev,
+                     const float *bp_dev, const void *w1_dev, const float *b1_dev, const float *w2_dev, float b2,
+                     float *logits_dev, float *values_dev, void *stream) {
+  using namespace aztower;
+  if (!feat_bf16_dev || !wp_dev || !bp_dev || !w1_dev || !b1_dev || !w2_dev || !logits_dev || !values_dev) { g_tower_err = "null argument"; return AZ_EINVAL; }
+  if (n_boards < 1 || (board_size != 9 && board_size != 15)) { g_tower_err = "n_boards >= 1, board_size 9 or 15"; return AZ_EINVAL; }
+  if (feat_stride < az_heads_feat_stride(board_size) || (feat_stride & 7)) { g_tower_err = "feat_stride: a multiple of 8, at least az_heads_feat_stride(board_size)"; return AZ_EINVAL; }
+  const dim3 grid((n_boards + 31) / 32), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (board_size == 15)
+    hipLaunchKernelGGL((k_heads<225>), grid, block, 0, s, (const uint16_t *)feat_bf16_dev, (int)feat_stride, (int)n_boards, (const char *)wp_dev,
+                       bp_dev, (const char *)w1_dev, b1_dev, w2_dev, b2, logits_dev, values_dev);
+  else
+    hipLaunchKernelGGL((k_heads<81>), grid, block, 0, s, (const uint16_t *)feat_bf16_dev, (int)feat_stride, (int)n_boards, (const char *)wp_dev,
+                       bp_dev, (const char *)w1_dev, b1_dev, w2_dev, b2, logits_dev, values_dev);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) { g_tower_err = std::string("k_heads launch: ") + hipGetErrorString(err); return AZ_EHIP; }
+  return AZ_OK;
+}
+
 int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
                      const void *packed_ring_dev, const void *packed_leaf_dev, const void *list_dev,
                      const void *count_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
-                     const float *headb_dev, float *pfeat_dev, float *vfeat_dev, void *stream) {
+                     const float *headb_dev, void *feat_bf16_dev, int32_t feat_stride, void *stream) {
   using namespace aztower;
-  if ((!x_bf16_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !pfeat_dev || !vfeat_dev ||
+  if ((!x_bf16_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !feat_bf16_dev ||
       (n_conv_layers > 0 && !wl_dev)) { g_tower_err = "null argument"; return AZ_EINVAL; }
   if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1)) { g_tower_err = "n_boards >= 1, even n_conv_layers"; return AZ_EINVAL; }
+  if (feat_stride < az_heads_feat_stride(board_size)) { g_tower_err = "feat_stride below az_heads_feat_stride(board_size)"; return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   hipError_t err;
   int dev = 0;
@@ -628,7 +741,7 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
                        (const int4 *)packed_leaf_dev, (const int32_t *)(use_list ? list_dev : nullptr),
                        (const int32_t *)(use_list ? count_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
-                       n_conv_layers, headw_dev, headb_dev, pfeat_dev, vfeat_dev, tickets);
+                       n_conv_layers, headw_dev, headb_dev, (uint16_t *)feat_bf16_dev, (int)feat_stride, tickets);
     return AZ_OK;
   };
   int rc;

@@ -40,7 +40,7 @@ class AzStats(C.Structure):
 EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check", "az_reset_games",
            "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_root_policy",
            "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
-           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_augment_samples", "az_leaf_buffers", "az_compact_leaves"]
+           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_heads_forward", "az_heads_feat_stride", "az_augment_samples", "az_leaf_buffers", "az_compact_leaves"]
 
 _lib = None
 
@@ -77,7 +77,10 @@ def load_library() -> C.CDLL:
     lib.az_reset_stats.argtypes = [vp, vp]
     lib.az_eval_hash.argtypes = [vp, vp, C.c_float, vp, vp, vp]
     lib.az_augment_samples.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
-    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]
+    lib.az_heads_forward.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
+    lib.az_heads_feat_stride.argtypes = [C.c_int32]
+    lib.az_heads_feat_stride.restype = C.c_int32
     lib.az_compact_leaves.argtypes = [vp, vp]
     lib.az_leaf_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.az_tower_last_error.argtypes = []

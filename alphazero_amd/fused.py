@@ -1,7 +1,7 @@
 """Fused evaluator for GomokuModel-family networks (examples/gomoku/model.py:41-90 and
 alphazero_amd.nets.GomokuNet): the conv tower runs as ONE hand-written bf16 MFMA kernel
 (csrc/az_tower.hip, activations resident in LDS); eval-mode BatchNorm is folded into the conv weights
-here; the heads' small Linear layers stay in PyTorch.  Same contract as the module it wraps:
+here; the heads' Linear layers run as one more small MFMA kernel (az_heads_forward).  Same contract as the module it wraps:
 ``(B, 9, N, N) -> (logits (B, N*N) f32, value (B, 1) f32)``.  Call ``refresh()`` after the module's
 weights change (load_state_dict / weight publish)."""
 from __future__ import annotations
@@ -30,6 +30,15 @@ def _pack3x3(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
         w = torch.cat([w, w.new_zeros(co, cin_pad - ci, 3, 3)], 1)
     t = w.permute(2, 3, 1, 0).reshape(9, cin_pad // 16, 2, 8, co)  # tap, ks, half, j, co
     return t.permute(0, 1, 2, 4, 3).contiguous().to(torch.bfloat16)
+
+
+def _pack_linear(w: torch.Tensor, n_pad: int, k_pad: int, k_off_src: int = 0) -> torch.Tensor:
+    """(n, k) f32 Linear weight -> [n-tile][k-step][k-half 2][n 32][8 k] bf16, zero padded to (n_pad, k_pad)"""
+    n, k = w.shape
+    full = w.new_zeros(n_pad, k_pad)
+    full[:n, :k] = w
+    t = full.reshape(n_pad // 32, 32, k_pad // 16, 2, 8)  # nt, n, ks, half, j
+    return t.permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16)
 
 
 class FusedTowerEvaluator:
@@ -85,9 +94,18 @@ class FusedTowerEvaluator:
         self.headb = torch.cat([pb.view(1), vb.view(2)]).to(dev).contiguous()
         f = lambda t: t.detach().float().to(dev).contiguous()
         pl, v1, v2 = m._policy_head[4], m._value_head[4], m._value_head[6]
-        self.pl_wt, self.pl_b = f(pl.weight).t().contiguous(), f(pl.bias)
-        self.v1_wt, self.v1_b = f(v1.weight).t().contiguous(), f(v1.bias)
-        self.v2_wt, self.v2_b = f(v2.weight).t().contiguous(), f(v2.bias)
+        if v1.out_features != 64 or v2.out_features != 1:
+            raise EngineError("FusedTowerEvaluator: the value head must be Linear(2 N*N, 64) -> Linear(64, 1)")
+        n2 = self.n2
+        self.kp, self.kv = (n2 + 15) // 16 * 16, (2 * n2 + 15) // 16 * 16
+        self.feat_stride = int(self.lib.az_heads_feat_stride(self.board))
+        assert self.feat_stride == self.kp + self.kv
+        self.wp = _pack_linear(f(pl.weight), (n2 + 31) // 32 * 32, self.kp).to(dev)
+        self.bp = f(pl.bias)
+        self.w1 = _pack_linear(f(v1.weight), 64, self.kv).to(dev)
+        self.b1 = f(v1.bias)
+        self.w2 = f(v2.weight).reshape(-1)
+        self.b2 = float(v2.bias.detach().float().reshape(-1)[0])
 
     def __call__(self, x: torch.Tensor | None, logits_out: torch.Tensor | None = None, packed=None, n_boards: int = 0):
         """x: contiguous (B,9,N,N) bf16 batch, or None with packed = Engine.leaf_buffers() (ring, leaf[, list, count])
@@ -105,24 +123,29 @@ class FusedTowerEvaluator:
             ring_p, leaf_p = C.c_void_p(packed[0]), C.c_void_p(packed[1])
             list_p = C.c_void_p(packed[2]) if len(packed) > 3 and packed[2] else None
             count_p = C.c_void_p(packed[3]) if len(packed) > 3 and packed[3] else None
-        if B not in self._buf:
-            self._buf[B] = (torch.zeros(B, self.n2, device=self.device), torch.zeros(B, 2 * self.n2, device=self.device))
-        pfeat, vfeat = self._buf[B]
+        if B not in self._buf:  # zeroed once: the kernels never write the pad columns, and the heads multiply them by zero weights
+            self._buf[B] = (torch.zeros(B, self.feat_stride, dtype=torch.bfloat16, device=self.device),
+                            torch.empty(B, self.n2, device=self.device), torch.empty(B, device=self.device))
+        feat, logits_own, value = self._buf[B]
+        logits = logits_out if logits_out is not None else logits_own
+        if logits.dtype != torch.float32 or not logits.is_contiguous() or tuple(logits.shape) != (B, self.n2):
+            raise EngineError("FusedTowerEvaluator: logits_out must be a contiguous (B, N*N) float32 tensor")
         P = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if self.kernel_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         rc = self.lib.az_tower_forward(self.board, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
                                        list_p, count_p, P(self.w0), P(self.wl), P(self.bias),
-                                       P(self.headw), P(self.headb), P(pfeat), P(vfeat),
-                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+                                       P(self.headw), P(self.headb), P(feat), self.feat_stride, st)
         if rc != 0:
             raise EngineError(f"az_tower_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
         if self.kernel_events is not None:
             ev1.record()
             self.kernel_events.append((ev0, ev1))
-        logits = torch.addmm(self.pl_b, pfeat, self.pl_wt, out=logits_out) if logits_out is not None \
-            else torch.addmm(self.pl_b, pfeat, self.pl_wt)
-        hid = torch.relu_(torch.addmm(self.v1_b, vfeat, self.v1_wt))
-        value = torch.tanh_(torch.addmm(self.v2_b, hid, self.v2_wt))
+        rc = self.lib.az_heads_forward(self.board, B, P(feat), self.feat_stride, P(self.wp), P(self.bp), P(self.w1), P(self.b1),
+                                       P(self.w2), self.b2, P(logits), P(value), st)
+        if rc != 0:
+            raise EngineError(f"az_heads_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
+        value = value.view(B, 1)
         return logits, value

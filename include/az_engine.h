@@ -188,12 +188,26 @@ int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *log
  *   or NULL) only the listed slots are evaluated and only their rows of pfeat / vfeat are written;
  *   w0_dev [9][1][2][64][8] bf16, wl_dev [n_conv_layers][9][4][2][64][8] bf16 ([tap][k-step][k-half][co][8 ci]);
  *   bias_dev [1+n_conv_layers][64] f32; headw_dev [3][64] f32, headb_dev [3] f32 (policy, value0, value1);
- *   pfeat_dev (n_boards, N*N) f32 and vfeat_dev (n_boards, 2, N*N) f32 out: the inputs of the heads'
- *   Linear layers (which stay in PyTorch).  board_size N in {9, 15}. */
+ *   feat_bf16_dev (n_boards, feat_stride) bf16 out: the inputs of the heads' Linear layers, row layout
+ *   [policy N*N | zero pad to a multiple of 16 | value0 N*N | value1 N*N | zero pad to a multiple of 16];
+ *   feat_stride >= az_heads_feat_stride(N) elements; the pads are never written: hand in a zeroed buffer.
+ *   board_size N in {9, 15}.  Groups of boards are handed to workgroups through a ticket counter that lives in the
+ *   library (16 pairs per GPU, rotated per launch): at most 16 launches may be in flight on one GPU. */
 int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
                      const void *packed_ring_dev, const void *packed_leaf_dev, const void *list_dev,
                      const void *count_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
-                     const float *headb_dev, float *pfeat_dev, float *vfeat_dev, void *stream);
+                     const float *headb_dev, void *feat_bf16_dev, int32_t feat_stride, void *stream);
+
+/* The heads' Linear layers of the same network family (examples/gomoku/model.py:69-72, 84-90) for the whole batch:
+ *   logits = feat[:, :N*N] @ Wp^T + bp;   value = tanh(relu(feat[:, KP:KP+2N*N] @ W1^T + b1) @ w2 + b2)
+ * as bf16 MFMA GEMMs with f32 accumulation.  feat as written by az_tower_forward;
+ *   wp_dev [ceil(N*N/32)][KP/16][2][32][8] bf16 and w1_dev [2][KV/16][2][32][8] bf16: [output tile][k-step][k-half][output][8 k],
+ *   zero padded (KP, KV = N*N and 2*N*N rounded up to 16); bp_dev (N*N) f32, b1_dev (64) f32, w2_dev (64) f32, b2;
+ *   logits_dev (n_boards, N*N) f32 and values_dev (n_boards) f32 out (every row is computed). */
+int32_t az_heads_feat_stride(int32_t board_size);
+int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16_dev, int32_t feat_stride, const void *wp_dev,
+                     const float *bp_dev, const void *w1_dev, const float *b1_dev, const float *w2_dev, float b2,
+                     float *logits_dev, float *values_dev, void *stream);
 const char *az_tower_last_error(void);
 
 #ifdef __cplusplus

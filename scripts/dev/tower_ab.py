@@ -23,20 +23,20 @@ if os.environ.get("ZERO"):  # all-zero weights and inputs: same instruction stre
     ev.w0.zero_(); ev.wl.zero_(); x.zero_()
 ref_p, ref_v = ev(x)
 ref_p, ref_v = ref_p.clone(), ref_v.clone()
-pfeat, vfeat = ev._buf[B]
-ref_pf = pfeat.clone()
+pfeat = ev._buf[B][0]
+ref_pf = pfeat.float().clone()
 P = lambda t: C.c_void_p(t.data_ptr())
 libs = []
 for path in sys.argv[1:]:
     lib = C.CDLL(os.path.join(ROOT, path))
-    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 13
+    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + [C.c_int32, C.c_void_p]
     libs.append((path, lib))
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def run(lib):
     rc = lib.az_tower_forward(board, B, ev.n_layers, P(x), None, None, None, None, P(ev.w0), P(ev.wl), P(ev.bias),
-                              P(ev.headw), P(ev.headb), P(pfeat), P(vfeat), st)
+                              P(ev.headw), P(ev.headb), P(pfeat), ev.feat_stride, st)
     assert rc == 0, rc
 
 
@@ -45,7 +45,7 @@ for p, lib in libs:
     pfeat.zero_()
     run(lib)
     torch.cuda.synchronize()
-    d = float((pfeat - ref_pf).abs().max())
+    d = float((pfeat.float() - ref_pf).abs().max())
     print(f"{p}: max |pfeat - default lib| = {d:.3g}")
 for rep in range(5):
     for p, lib in libs:
