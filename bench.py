@@ -222,14 +222,20 @@ def main():
         eng.check()
 
     ev_sel, ev_exp, ev_nn, ev_tower = [], [], [], []
+    EVENT_EVERY = 8  # every 8th simulation step of the timed region is bracketed with HIP events
 
     def timed_round():
         """run.move_round with HIP events around each tree kernel and each network forward"""
-        if run.fused is not None:
-            run.fused.kernel_events = ev_tower  # events around the tower kernel alone, inside FusedTowerEvaluator
         noise = run.draw_noise()
         eng.begin_search()
-        for _ in range(sims):
+        for k in range(sims):
+            if k % EVENT_EVERY:  # un-bracketed simulation step (an event record costs the stream ~5 us)
+                if run.fused is not None:
+                    run.fused.kernel_events = None
+                run.sim_step(noise)
+                continue
+            if run.fused is not None:
+                run.fused.kernel_events = ev_tower  # events around the tower kernel alone, inside FusedTowerEvaluator
             a, b, c, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
             a.record()
             eng.select_gather(None if run.fused is not None else run.nn_input)
@@ -301,7 +307,7 @@ def main():
             return max(sum(a.elapsed_time(b) for a, b in pairs) / max(len(pairs), 1) - ev_overhead, 1e-6)
 
         nin = d.nn_channels * d.height * d.width
-        launches = max(len(ev_sel), 1)
+        launches = sims * (1 if args.graph else args.steps)  # launches of each per-simulation kernel behind st_probe
         sel_ms, exp_ms, nn_ms = mean_ms(ev_sel), mean_ms(ev_exp), mean_ms(ev_nn)
         st_all, st = st, st_probe  # byte counts must come from the same launches the events bracket
         # algorithmic bytes: child record = Q f64 + {P f32, N i32} + meta u32 = 20 B read by select,
