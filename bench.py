@@ -166,6 +166,8 @@ def main():
         model = model.to(tdtype)
     model = model.to(memory_format=torch.channels_last)
     publisher = WeightPublisher(model, src=0)
+    torch.manual_seed(1234 + rank)  # same weights on every rank (make_model seeds 0), different games: per-rank RNG streams
+    torch.cuda.manual_seed(1234 + rank)
 
     eng = Engine(game, slots, sims, board_size=n, nn_dtype=tdtype, device=dev)
     d = eng.dims
