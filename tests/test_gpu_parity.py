@@ -82,6 +82,79 @@ def test_search_matches_oracle_hash_net(oracle, name, game, n, sims, nn_dtype):
     assert st["sims"] == G * sims and st["evals"] + st["terminals"] == st["sims"]
 
 
+class _LineNet(torch.nn.Module):
+    """Prior sharply peaked on the lowest-numbered EMPTY cell (so it is always legal), values of a few 1e-5: the search
+    walks one line, a ply deeper per simulation.  Integer-valued arithmetic: identical on CPU and GPU."""
+
+    def __init__(self):
+        super().__init__()
+        self.anchor = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        B = x.shape[0]
+        newest = x[:, 7].reshape(B, -1).float()
+        A = newest.shape[1]
+        idx = torch.arange(A, device=x.device, dtype=torch.float32)
+        logits = torch.where(newest == 0, -50.0 * idx, torch.full_like(newest, -1.0e4))
+        s = x.reshape(B, -1).float().sum(1)
+        value = (torch.remainder(s, 7.0) - 3.0) * 1.0e-5
+        return logits, value.view(B, 1)
+
+
+@pytest.mark.parametrize("name,game,n,sims,moves", [("gomoku15", 2, 15, 220, 0), ("gomoku15", 2, 15, 150, 40), ("gomoku9", 2, 9, 120, 3)])
+def test_deep_narrow_trees_match_oracle(oracle, name, game, n, sims, moves):
+    """One-line searches: paths far longer than a wavefront is wide (the backup's second loop), a terminal leaf at the
+    end of the line that is revisited by every later simulation, mid-game roots."""
+    rng = np.random.default_rng(11)
+    G = 6
+    d = oracle.dims(game, n)
+    eng = _engine(game, n, G, sims)
+    pos = [_random_position(oracle, game, n, moves, rng) for _ in range(G)]
+    for g, (h, p) in enumerate(pos):
+        eng.set_position(g, h, p)
+    net = _LineNet().cuda()
+
+    def evaluator(x, l, v):
+        p, val = net(x)
+        l.copy_(p)
+        v.copy_(val.view(-1))
+
+    pi, visits, q, prior = _run_search(eng, sims, evaluator, None)
+    st = eng.read_stats()
+    ev = oracle.torch_eval(_LineNet(), (d["cin"], d["H"], d["W"]))
+    for g, (h, p) in enumerate(pos):
+        r = oracle.search(game, n, h[-1], p, h, sims, ev, noise=None)
+        assert np.array_equal(visits[g], r["visits"]), (name, g)
+        assert np.array_equal(q[g], r["child_q"]), (name, g)
+        assert np.array_equal(pi[g], r["pi"]), (name, g)
+    if moves == 0:
+        assert st["sum_depth"] / st["sims"] > 40 and st["terminals"] > 0, st
+
+
+def test_all_legal_priors_underflow_is_an_error_like_the_reference():
+    """When softmax puts all its mass on ILLEGAL moves, `p /= p.sum()` (core/MCTS_alphazero.py:191) is 0/0: every prior is
+    NaN, no PUCT score compares greater, `select` returns None and the reference dies with an AttributeError on the next
+    line (:150-152).  The engine raises its device error flag instead of walking into an empty block."""
+    from alphazero_amd.engine import EngineError
+
+    eng = _engine(0, 3, 2, 8)
+    hist = np.zeros((8, 9), np.float32)
+    hist[-1, 4] = 1.0  # the centre is taken ...
+    for g in range(2):
+        eng.set_position(g, hist, -1)
+    nn = eng.new_nn_input()
+    logits, values = eng.new(2, 9), eng.new(2)
+    logits.fill_(-1000.0)
+    logits[:, 4] = 1000.0  # ... and the network wants exactly that cell: exp() of every legal logit underflows to 0
+    values.zero_()
+    eng.begin_search()
+    for _ in range(3):
+        eng.select_gather(nn)
+        eng.expand_backup(logits, values, None)
+    with pytest.raises(EngineError):
+        eng.check()
+
+
 SEARCH = load_cases("search.npz")
 
 
