@@ -50,10 +50,11 @@ class WeightPublisher:
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
 
     @torch.no_grad()
-    def publish(self) -> int:
+    def publish(self, force: bool = False) -> int:
+        """-> bytes broadcast (0 when there is nobody to publish to; force=True runs the collective even with one rank)"""
         import torch.distributed as dist
 
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
             return 0
         off = 0
         if dist.get_rank() == self.src:

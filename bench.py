@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--preroll", type=int, default=96, help="cheap 2-sim move rounds that stagger game ages")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the "
+                    "barrier / all-reduce / weight-broadcast path on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,9 +155,12 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     game, n, sims, slots, _ = WORKLOADS[args.workload]
     sims = args.sims or sims
@@ -254,7 +259,7 @@ def main():
         return run.done
 
     def step(timed: bool):
-        if publisher.publish() and run.fused is not None:  # learner -> self-play weight push (RCCL broadcast; no-op at N = 1)
+        if publisher.publish(force=args.force_dist) and run.fused is not None:  # learner -> self-play weight push (RCCL broadcast; no-op at N = 1)
             run.fused.refresh()  # re-fold BatchNorm / re-pack the published weights for the fused tower
         done = timed_round() if (timed and not args.graph) else run.move_round(inv_tao)[1]
         collect(done)
@@ -265,14 +270,14 @@ def main():
     eng.reset_stats()
     finished_games = finished_plies = 0
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -289,7 +294,7 @@ def main():
         st_probe = st
 
     tt = torch.tensor([elapsed, float(st["sims"]), float(finished_games), float(finished_plies)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -391,7 +396,7 @@ def main():
         if cpu:
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

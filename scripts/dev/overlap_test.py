@@ -56,5 +56,5 @@ def bench(parts, graph, moves=3):
     del ers
 
 
-for parts, graph in ((1, False), (2, False), (1, True), (2, True), (4, True)):
+for parts, graph in ((1, False), (2, False), (2, True)):
     bench(parts, graph)
