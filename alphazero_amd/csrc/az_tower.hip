@@ -604,68 +604,86 @@ __global__ __launch_bounds__(256, 2) void k_heads(const uint16_t *__restrict__ f
                                                   float *__restrict__ logits, float *__restrict__ values) {
   constexpr int KP = (NV + 15) / 16 * 16, KSP = KP / 16, NTP = (NV + 31) / 32;
   constexpr int KV = (2 * NV + 15) / 16 * 16, KSV = KV / 16, KH = (KSV + 1) / 2;
-  __shared__ float part[4][32][33];
-  __shared__ float vsum[2][32];
+  constexpr int MT = 1;  // 32-board tiles per workgroup (2 measured slower, 31.6 vs 23.0 us: half as many workgroups to hide the L2 latency)
+  __shared__ float part[4][MT * 32][33];
+  __shared__ float vsum[2][MT * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int g0 = blockIdx.x * 32;
-  const int gr = min(g0 + r, G - 1);  // rows past the batch are computed on a copy of the last row and not stored
-  const uint16_t *fa = feat + (size_t)gr * FS + 8 * h;
+  const int g0 = blockIdx.x * (MT * 32);
+  const uint16_t *fa[MT];  // rows past the batch are computed on a copy of the last row and not stored
+#pragma unroll
+  for (int m = 0; m < MT; ++m) fa[m] = feat + (size_t)min(g0 + m * 32 + r, G - 1) * FS + 8 * h;
   // ---- policy
   for (int nt = wave; nt < NTP; nt += 4) {
-    f32x16 acc;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][i] = 0.0f;
     const char *wb = wp + ((size_t)nt * KSP * 2 + h) * 512 + r * 16;
 #pragma unroll
     for (int ks = 0; ks < KSP; ++ks) {
-      const bf16x8 a = *(const bf16x8 *)(fa + ks * 16);
       const bf16x8 b = *(const bf16x8 *)(wb + (size_t)ks * 1024);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const bf16x8 a = *(const bf16x8 *)(fa[m] + ks * 16);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
+      }
     }
     const int n = nt * 32 + r;
-    const float bias = n < NV ? bp[n] : 0.0f;
     if (n < NV) {
+      const float bias = bp[n];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (g0 + row < G) logits[(size_t)(g0 + row) * NV + n] = acc[i] + bias;
-      }
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (g0 + row < G) logits[(size_t)(g0 + row) * NV + n] = acc[m][i] + bias;
+        }
     }
   }
   // ---- value: hidden tile (wave & 1), K half (wave >> 1)
   {
     const int nt = wave & 1, kh = wave >> 1;
-    f32x16 acc;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][i] = 0.0f;
     const char *wb = w1 + ((size_t)nt * KSV * 2 + h) * 512 + r * 16;
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
       const int ks = kh * KH + k;
       if (ks < KSV) {
-        const bf16x8 a = *(const bf16x8 *)(fa + KP + ks * 16);
         const bf16x8 b = *(const bf16x8 *)(wb + (size_t)ks * 1024);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const bf16x8 a = *(const bf16x8 *)(fa[m] + KP + ks * 16);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i];
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) part[wave][m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[m][i];
     __syncthreads();
     if (wave < 2) {
       const int n = wave * 32 + r;
       const float bn = b1[n], wn = w2[n];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        float t = fmaxf(part[wave][row][r] + part[wave + 2][row][r] + bn, 0.0f) * wn;
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-        if (r == 0) vsum[wave][row] = t;
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int row = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float t = fmaxf(part[wave][row][r] + part[wave + 2][row][r] + bn, 0.0f) * wn;
+#pragma unroll
+          for (int off = 16; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+          if (r == 0) vsum[wave][row] = t;
+        }
     }
     __syncthreads();
-    if (tid < 32 && g0 + tid < G) values[g0 + tid] = tanhf(vsum[0][tid] + vsum[1][tid] + b2);
+    if (tid < MT * 32 && g0 + tid < G) values[g0 + tid] = tanhf(vsum[0][tid] + vsum[1][tid] + b2);
   }
 }
 
@@ -697,7 +715,7 @@ int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16
   if (!feat_bf16_dev || !wp_dev || !bp_dev || !w1_dev || !b1_dev || !w2_dev || !logits_dev || !values_dev) { g_tower_err = "null argument"; return AZ_EINVAL; }
   if (n_boards < 1 || (board_size != 9 && board_size != 15)) { g_tower_err = "n_boards >= 1, board_size 9 or 15"; return AZ_EINVAL; }
   if (feat_stride < az_heads_feat_stride(board_size) || (feat_stride & 7)) { g_tower_err = "feat_stride: a multiple of 8, at least az_heads_feat_stride(board_size)"; return AZ_EINVAL; }
-  const dim3 grid((n_boards + 31) / 32), block(256);
+  const dim3 grid((n_boards + 31) / 32), block(256);  // k_heads: MT * 32 boards per workgroup
   hipStream_t s = (hipStream_t)stream;
   if (board_size == 15)
     hipLaunchKernelGGL((k_heads<225>), grid, block, 0, s, (const uint16_t *)feat_bf16_dev, (int)feat_stride, (int)n_boards, (const char *)wp_dev,
