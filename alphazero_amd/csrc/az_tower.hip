@@ -1,26 +1,30 @@
-// az_tower.hip -- fused residual conv tower (policy/value trunk + head 1x1 convs) for MI355X.
+// az_tower.hip -- fused residual conv tower (policy/value trunk + head 1x1 convs) and the heads' Linear layers, for MI355X.
 //
 // No counterpart in the reference beyond the model contract (nn_models/base.py:17-19): it evaluates
 // the GomokuModel family of examples/gomoku/model.py:41-90 -- conv3x3(9->64)+BN+ReLU, `blocks` residual
-// blocks of two conv3x3(64->64)+BN, then the 1x1 head convs+BN+ReLU -- in ONE kernel, with the board's
+// blocks of two conv3x3(64->64)+BN, then the 1x1 head convs+BN+ReLU -- in ONE kernel (k_tower), with the board's
 // activations resident in LDS for the whole tower and every conv an implicit GEMM on bf16 MFMA
-// (v_mfma_f32_32x32x16_bf16, f32 accumulate).  BatchNorm (eval mode) is folded into the conv weights
-// and a per-channel bias by the host (alphazero_amd/fused.py).  The two small head Linear layers stay
-// in PyTorch (hipBLASLt).  C ABI at the bottom; declared in include/az_engine.h.
+// (v_mfma_f32_32x32x16_bf16, f32 accumulate), and the heads' Linear layers in a second small kernel (k_heads).
+// BatchNorm (eval mode) is folded into the conv weights and a per-channel bias by the host (alphazero_amd/fused.py).
+// C ABI at the bottom; declared in include/az_engine.h.
 //
-// Mapping (one workgroup = 4 waves = BPW boards):
+// k_tower (one workgroup = 4 waves = BPW boards at a time; persistent, two workgroups per CU):
 //   LDS act[cell][64 ch] bf16, cells packed without halo (cell = board*N*N + row*N + col), 128 B per
 //   cell, the eight 16-byte channel chunks of a cell XOR-swizzled with (cell>>1)&7: the 32 lanes of a
 //   position tile hold 32 CONSECUTIVE cells, a tap shifts all of them by the same amount, so the 16
 //   lanes of every ds_read_b128 group hit 16 different bank quads (conflict-free).  Taps that fall off
-//   the board read a 16-byte zero slot instead (per-lane 9-bit tap-validity mask).
+//   the board read a 128-byte zero row instead (per-lane 9-bit tap-validity mask).
 //   GEMM orientation: D[co][pos] = sum_k W[co][k] * X[k][pos], k = (tap, ci).  A = weights (rows = out
 //   channels), B = activations (cols = positions): the accumulator then holds, per lane, ONE position
 //   and 4-channel runs, which pack into 8-byte LDS stores in the epilogue.
 //   8 position tiles of 32 (2 per wave) x 2 channel tiles of 32: 4 accumulators (64 VGPRs) per wave.
-//   Per tap the 64x64 weight slice (8 KiB) is staged global -> registers -> LDS, double buffered, and
-//   shared by the 4 waves; the layer is computed in place (outputs stay in accumulators until every
-//   wave has finished reading the input, then overwrite it); the residual is kept in registers.
+//   Weights: one kernel row (3 taps, 24 KiB) per stage, global -> LDS by LDS-DMA, double buffered, shared by
+//   the 4 waves, issued under the running stage's MFMAs; fragment reads software pipelined by hand (inline-asm
+//   ds_read_b128 + counted lgkmcnt waits).  The layer is computed in place (outputs stay in accumulators until
+//   every wave has finished reading the input, then overwrite it); the residual is kept in registers; the
+//   accumulators start at bias (+ residual), the epilogue is ReLU + pack + store.
+//   Boards are handed out by a ticket counter (see the kernel); biases and the next board's packed input
+//   arrive by LDS-DMA ahead of their use.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
