@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/az_engine.h"
@@ -700,6 +701,7 @@ static std::string g_tower_err;
 // engines on two streams).  A __device__ array exists once per GPU; its address is looked up per device.
 #define AZ_TOWER_TICKET_PAIRS 16
 static __device__ unsigned int g_tower_tickets[2 * AZ_TOWER_TICKET_PAIRS];
+static std::mutex g_ticket_mutex;  // engines on different host threads may launch towers on the same GPU
 static unsigned int *g_ticket_base[64];
 static unsigned int g_ticket_seq[64];
 
@@ -745,15 +747,19 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
   hipError_t err;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { g_tower_err = "hipGetDevice failed"; return AZ_EHIP; }
-  if (g_ticket_base[dev] == nullptr) {
-    void *p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tower_tickets)) != hipSuccess || p == nullptr) {
-      g_tower_err = "hipGetSymbolAddress(g_tower_tickets) failed";
-      return AZ_EHIP;
+  unsigned int *tickets = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_ticket_mutex);
+    if (g_ticket_base[dev] == nullptr) {
+      void *p = nullptr;
+      if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tower_tickets)) != hipSuccess || p == nullptr) {
+        g_tower_err = "hipGetSymbolAddress(g_tower_tickets) failed";
+        return AZ_EHIP;
+      }
+      g_ticket_base[dev] = (unsigned int *)p;
     }
-    g_ticket_base[dev] = (unsigned int *)p;
+    tickets = g_ticket_base[dev] + 2 * (g_ticket_seq[dev]++ % AZ_TOWER_TICKET_PAIRS);
   }
-  unsigned int *tickets = g_ticket_base[dev] + 2 * (g_ticket_seq[dev]++ % AZ_TOWER_TICKET_PAIRS);
   auto launch = [&](auto kern, size_t lds, int bpw) -> int {
     if (lds > 160 * 1024) { g_tower_err = "tower geometry exceeds the CU's LDS"; return AZ_EINVAL; }
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
