@@ -131,34 +131,44 @@ class SelfPlayRunner:
         self.evaluate()
         self.e.expand_backup(self.logits, self.values, noise)
 
+    def eval_step(self, noise) -> None:
+        """the repeating unit of a search whose first descent is already out: network -> (expand+backup of this
+        simulation and select+gather of the next one, in one launch)"""
+        self.evaluate()
+        self.e.expand_select(self.logits, self.values, noise, None if self.fused is not None else self.nn_input)
+
     def _capture(self, noise) -> None:
-        """Capture one simulation step into a HIP graph (all buffers are persistent, the launches are
-        plain kernel launches on the capture stream): the inner loop is launch-bound for the small games."""
+        """Capture the repeating unit into a HIP graph (all buffers are persistent, the launches are plain kernel
+        launches on the capture stream): the inner loop is launch-bound for the small games."""
         s = torch.cuda.Stream(self.e.device)
         s.wait_stream(torch.cuda.current_stream(self.e.device))
         with torch.cuda.stream(s):
+            self.e.select_gather(None if self.fused is not None else self.nn_input)
             for _ in range(2):  # warm up allocator / library handles outside capture (results are discarded by
-                self.sim_step(noise)  # the begin_search that follows)
+                self.eval_step(noise)  # the begin_search that follows)
         torch.cuda.current_stream(self.e.device).wait_stream(s)
         torch.cuda.synchronize(self.e.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.sim_step(noise)
+            self.eval_step(noise)
         self._graph, self._graph_noise = g, noise is not None
 
     def search(self) -> None:
-        """num_sims simulations in every active tree (MCTS.search, core/MCTS_alphazero.py:128-178)"""
+        """num_sims simulations in every active tree (MCTS.search, core/MCTS_alphazero.py:128-178): one descent, then
+        num_sims - 1 x (network, backup + next descent), then the last network evaluation and backup"""
         noise = self.draw_noise()
         e = self.e
         if self.use_graph and (self._graph is None or self._graph_noise != (noise is not None)):
             self._capture(noise)
         e.begin_search()
-        if self._graph is not None and self.use_graph:
-            for _ in range(self.num_sims):
+        e.select_gather(None if self.fused is not None else self.nn_input)
+        for _ in range(self.num_sims - 1):
+            if self._graph is not None and self.use_graph:
                 self._graph.replay()
-            return
-        for _ in range(self.num_sims):
-            self.sim_step(noise)
+            else:
+                self.eval_step(noise)
+        self.evaluate()
+        e.expand_backup(self.logits, self.values, noise)
 
     def move_round(self, inv_tao: torch.Tensor, forced: Optional[torch.Tensor] = None):
         """search + temperature sampling + step, for every active slot (training/self_play.py:36-83)"""

@@ -182,8 +182,7 @@ __device__ __forceinline__ void load_ring(const uint32_t *tb, int ply, uint32_t 
 // One dependent memory round trip per level: the three child streams are read together, and the winner's
 // meta word and visit count travel through the argmax butterfly, so nothing is re-read.
 template <class GT, typename OutT>
-__global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
-  const int g = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input, const int g, const int lane) {
   __shared__ uint32_t hist[8][GT::SW];
   __shared__ uint32_t cur[GT::SW];
   const bool slotActive = v.active[g] != 0;  // one batch with the other per-slot words
@@ -292,6 +291,11 @@ __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
   }
 }
 
+template <class GT, typename OutT>
+__global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
+  select_gather_body<GT, OutT>(v, nn_input, blockIdx.x, threadIdx.x);
+}
+
 // Compact list of the slots whose leaf needs the network, in slot order: one workgroup; each thread owns a
 // contiguous run of `per` slots (a multiple of 16) whose byte flags it reads 16 at a time, then a block-wide scan
 // of the per-thread counts in LDS.  (A single atomic counter bumped by 16,384 waves costs ~190 us: one word takes
@@ -328,9 +332,8 @@ __global__ __launch_bounds__(1024) void k_compact_leaves(View v, int per) {
 // ------------------------------------------------------------------------- expand + backup ----
 // MCTS._get_prior :180-192, MCTSNode.expand :43-57, MCTSNode.update :80-88, MCTS._bacaward :194-200.
 template <class GT>
-__global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logits, const float *values,
-                                                      const float *noise) {
-  const int g = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void expand_backup_body(const View &v, const float *logits, const float *values, const float *noise,
+                                                   const int g, const int lane) {
   const bool slotActive = v.active[g] != 0;  // tested after the batch below is on its way (all of it is valid memory)
   __shared__ uint32_t st[GT::SW];
   constexpr int A = GT::A, NI = (A + 63) / 64;
@@ -470,6 +473,24 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
     v.rootN[g] = n;
     v.rootQ[g] = rootQ + (val - rootQ) / (double)n;
   }
+}
+
+template <class GT>
+__global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logits, const float *values,
+                                                      const float *noise) {
+  expand_backup_body<GT>(v, logits, values, noise, blockIdx.x, threadIdx.x);
+}
+
+// The end of simulation i and the beginning of simulation i+1 of the same tree in one launch (the search loop
+// alternates network <-> tree, so this halves the tree launches and their dispatch gaps).  The descent re-reads
+// records the backup has just written -- by the same wavefront, through the same L1: a workgroup-scope fence (what
+// __syncthreads() carries) orders them.  (An agent-scope __threadfence() here writes back the L2 once per wave: 590 us.)
+template <class GT, typename OutT>
+__global__ __launch_bounds__(64) void k_expand_select(View v, const float *logits, const float *values, const float *noise,
+                                                      OutT *nn_input) {
+  expand_backup_body<GT>(v, logits, values, noise, blockIdx.x, threadIdx.x);
+  __syncthreads();
+  select_gather_body<GT, OutT>(v, nn_input, blockIdx.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------- root policy --------
@@ -987,6 +1008,19 @@ int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_
   if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_backup<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, logits_dev, values_dev, noise_dev));
   return launch_check(e, "k_expand_backup");
+}
+
+int az_expand_select(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev, void *nn_input_dev,
+                     void *stream) {
+  if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
+  const dim3 grid(e->v.G), block(64);
+  hipStream_t s = (hipStream_t)stream;
+  switch (e->cfg.nn_dtype) {
+    case AZ_NN_F32: AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_select<GT, float>), grid, block, 0, s, e->v, logits_dev, values_dev, noise_dev, (float *)nn_input_dev)); break;
+    case AZ_NN_BF16: AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_select<GT, bf16_t>), grid, block, 0, s, e->v, logits_dev, values_dev, noise_dev, (bf16_t *)nn_input_dev)); break;
+    default: AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_select<GT, f16_t>), grid, block, 0, s, e->v, logits_dev, values_dev, noise_dev, (f16_t *)nn_input_dev)); break;
+  }
+  return launch_check(e, "k_expand_select");
 }
 
 int az_root_policy(az_engine *e, float *pi_dev, int32_t *visits_dev, double *child_q_dev, float *root_prior_dev, void *stream) {

@@ -38,7 +38,7 @@ class AzStats(C.Structure):
 
 
 EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check", "az_reset_games",
-           "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_root_policy",
+           "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_expand_select", "az_root_policy",
            "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
            "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_heads_forward", "az_heads_feat_stride", "az_augment_samples", "az_leaf_buffers", "az_compact_leaves"]
 
@@ -68,6 +68,7 @@ def load_library() -> C.CDLL:
     lib.az_begin_search.argtypes = [vp, vp]
     lib.az_select_gather.argtypes = [vp, vp, vp]
     lib.az_expand_backup.argtypes = [vp, vp, vp, vp, vp]
+    lib.az_expand_select.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.az_root_policy.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.az_root_nn_state.argtypes = [vp, vp, vp]
     lib.az_play_moves.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -229,6 +230,17 @@ class Engine:
         self._expect(values, (self.n_slots,), torch.float32, "values")
         self._expect(noise, (self.n_slots, A), torch.float32, "noise")
         self._ck(self.lib.az_expand_backup(self._h, _ptr(logits), _ptr(values), _ptr(noise), self._stream()))
+
+    def expand_select(self, logits, values, noise=None, nn_input=None):
+        """expand_backup of the running simulation + select_gather of the next one, in one launch"""
+        d = self.dims
+        self._expect(logits, (self.n_slots, d.n_action), torch.float32, "logits")
+        if values.dim() == 2:
+            values = values.view(-1)
+        self._expect(values, (self.n_slots,), torch.float32, "values")
+        self._expect(noise, (self.n_slots, d.n_action), torch.float32, "noise")
+        self._expect(nn_input, (self.n_slots, d.nn_channels, d.height, d.width), self.nn_dtype, "nn_input")
+        self._ck(self.lib.az_expand_select(self._h, _ptr(logits), _ptr(values), _ptr(noise), _ptr(nn_input), self._stream()))
 
     def root_policy(self, pi=None, visits=None, child_q=None, root_prior=None):
         A, G = self.dims.n_action, self.n_slots

@@ -16,8 +16,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                   bound): the convolutions' algorithmic flops for the boards one launch evaluates / mean launch time
                   (HIP events on the launch stream around the kernel alone), vs 2.5 PFLOP/s dense bf16.  Otherwise the
                   slower tree kernel (HBM bound).
-  roofline_tree-- the slower hand-written tree kernel (k_select_gather / k_expand_backup): algorithmic bytes per
-                  launch / mean launch time, vs 8 TB/s HBM.
+  roofline_tree-- the hand-written tree kernel of a simulation step (k_expand_select: backup of simulation i + descent
+                  of simulation i+1 in one launch): algorithmic bytes per launch / mean launch time, vs 8 TB/s HBM.
   nn_eval      -- the whole network forward (tower + head linears, or PyTorch/MIOpen with --evaluator model):
                   achieved TFLOP/s on the boards actually evaluated vs 2.5 PFLOP/s dense bf16.
   cpu_baseline -- the CPU oracle (oracle/, "port" of the reference path, proven equal to it on the
@@ -228,30 +228,34 @@ def main():
         run.num_sims = sims
         eng.check()
 
-    ev_sel, ev_exp, ev_nn, ev_tower = [], [], [], []
+    ev_tree, ev_nn, ev_tower = [], [], []
     EVENT_EVERY = 8  # every 8th simulation step of the timed region is bracketed with HIP events
 
     def timed_round():
         """run.move_round with HIP events around each tree kernel and each network forward"""
         noise = run.draw_noise()
+        nn_in = None if run.fused is not None else run.nn_input
         eng.begin_search()
-        for k in range(sims):
+        eng.select_gather(nn_in)  # the move's first descent; every later one rides with the previous simulation's backup
+        for k in range(sims - 1):
             if k % EVENT_EVERY:  # un-bracketed simulation step (an event record costs the stream ~5 us)
                 if run.fused is not None:
                     run.fused.kernel_events = None
-                run.sim_step(noise)
+                run.eval_step(noise)
                 continue
             if run.fused is not None:
                 run.fused.kernel_events = ev_tower  # events around the tower kernel alone, inside FusedTowerEvaluator
-            a, b, c, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+            a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             a.record()
-            eng.select_gather(None if run.fused is not None else run.nn_input)
-            b.record()
             run.evaluate()
+            b.record()
+            eng.expand_select(run.logits, run.values, noise, nn_in)
             c.record()
-            eng.expand_backup(run.logits, run.values, noise)
-            e2.record()
-            ev_sel.append((a, b)); ev_nn.append((b, c)); ev_exp.append((c, e2))
+            ev_nn.append((a, b)); ev_tree.append((b, c))
+        if run.fused is not None:
+            run.fused.kernel_events = None
+        run.evaluate()
+        eng.expand_backup(run.logits, run.values, noise)
         if run.fused is not None:
             run.fused.kernel_events = None
         run.draw_expo()
@@ -315,7 +319,7 @@ def main():
 
         nin = d.nn_channels * d.height * d.width
         launches = sims * (1 if args.graph else args.steps)  # launches of each per-simulation kernel behind st_probe
-        sel_ms, exp_ms, nn_ms = mean_ms(ev_sel), mean_ms(ev_exp), mean_ms(ev_nn)
+        tree_ms, nn_ms = mean_ms(ev_tree), mean_ms(ev_nn)
         st_all, st = st, st_probe  # byte counts must come from the same launches the events bracket
         # algorithmic bytes: child record = Q f64 + {P f32, N i32} + meta u32 = 20 B read by select,
         # 12 B written at expansion (Q is not stored until the first visit);
@@ -325,7 +329,8 @@ def main():
                      + st["sims"] * (16.0 + 36.0 * d.state_words + 16.0)) / launches
         exp_bytes = (st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 12.0 * st["expanded_edges"]
                      + 32.0 * st["sum_depth"] + 36.0 * st["sims"]) / launches
-        dom = ("k_select_gather", sel_bytes, sel_ms) if sel_ms >= exp_ms else ("k_expand_backup", exp_bytes, exp_ms)
+        # the tree work of a simulation step is ONE launch: backup of simulation i + descent of simulation i+1
+        dom = ("k_expand_select", sel_bytes + exp_bytes, tree_ms)
 
         # HBM traffic from PMC counters cannot be collected inside this run (separate rocprofv3 --pmc passes,
         # scripts/pmc_traffic.sh); the last committed measurement of this same workload is reported, if present
@@ -357,7 +362,7 @@ def main():
             nn_eval = {"bound": "mfma", "ms_per_batch": nn_ms, "achieved": fl / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
                        "peak": 2500.0, "unit": "TFLOP/s", "frac": (fl / (nn_ms * 1e-3) / 1e12 / 2500.0) if nn_ms else 0.0,
                        "flops_per_eval": model.flops_per_eval(), "boards_per_batch": evals_per_launch,
-                       "share_of_step": nn_ms / max(nn_ms + sel_ms + exp_ms, 1e-9),
+                       "share_of_step": nn_ms / max(nn_ms + tree_ms, 1e-9),
                        "implementation": "az_tower.hip fused bf16 MFMA tower + torch head linears" if args.evaluator == "fused"
                        else "PyTorch/MIOpen module forward"}
             if args.evaluator == "fused" and ev_tower:
@@ -369,7 +374,7 @@ def main():
                 roofline = {"bound": "mfma", "kernel": "k_tower", "achieved": tw_fl / (tw_ms * 1e-3) / 1e12, "peak": 2500.0,
                             "unit": "TFLOP/s", "frac": tw_fl / (tw_ms * 1e-3) / 1e12 / 2500.0, "traffic": ttraffic,
                             "traffic_note": tnote, "flops_per_launch": tw_fl, "boards_per_launch": evals_per_launch,
-                            "ms_per_launch": tw_ms, "share_of_step": tw_ms / max(nn_ms + sel_ms + exp_ms, 1e-9)}
+                            "ms_per_launch": tw_ms, "share_of_step": tw_ms / max(nn_ms + tree_ms, 1e-9)}
         out = {
             "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -381,8 +386,9 @@ def main():
             "mean_plies_per_finished_game": (total_plies / total_games) if total_games else None,
             "roofline": roofline,
             "roofline_tree": tree_roofline,
-            "tree_kernels": {"k_select_gather": {"ms": sel_ms, "bytes": sel_bytes, "GBps": sel_bytes / max(sel_ms, 1e-9) / 1e6},
-                             "k_expand_backup": {"ms": exp_ms, "bytes": exp_bytes, "GBps": exp_bytes / max(exp_ms, 1e-9) / 1e6},
+            "tree_kernels": {"k_expand_select": {"ms": tree_ms, "bytes": sel_bytes + exp_bytes,
+                                                 "GBps": (sel_bytes + exp_bytes) / max(tree_ms, 1e-9) / 1e6,
+                                                 "bytes_descent": sel_bytes, "bytes_expand_backup": exp_bytes},
                              "event_pair_overhead_ms": ev_overhead,
                              "timed_with": "probe step after the timed region (timed steps replay a HIP graph)" if args.graph
                              else "HIP events inside the timed region",

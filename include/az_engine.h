@@ -124,6 +124,12 @@ int az_compact_leaves(az_engine *e, void *stream);
 int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_dev,
                      const float *noise_dev, void *stream);
 
+/* az_expand_backup for the running simulation followed by az_select_gather for the next one, of every tree, in ONE
+ * launch: the search loop (MCTS.search :144-172) alternates network and tree work, so all but the first descent and the
+ * last backup of a move can go out this way (half the tree launches).  Same arguments and results as the two calls. */
+int az_expand_select(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev,
+                     void *nn_input_dev, void *stream);
+
 /* core/MCTS_alphazero.py:174-178: pi = visits / visits.sum() as (n_slots, A) f32.  Optional extras
  * (NULL to skip): root child visits i32 (n_slots, A), child values f64 (n_slots, A) from the child's
  * own view, the root prior f32 (n_slots, A). */
