@@ -87,12 +87,12 @@ class SelfPlayRunner:
             self.fused = FusedTowerEvaluator(model)
             if engine.game != GAME_GOMOKU or self.fused.board != engine.dims.height:
                 raise EngineError("the fused evaluator's board does not match the engine's game")
-            self._packed = engine.leaf_buffers()
+            ring, leaf, _, _, flags = engine.leaf_buffers()
+            self._packed = (ring, leaf, None, None, flags)  # flag mode: the tower skips terminal leaves by itself
 
     # one model forward on the gathered batch -> self.logits / self.values (f32, engine device)
     def evaluate(self) -> None:
         if self.fused is not None:
-            self.e.compact_leaves()  # terminal leaves cost no network evaluation
             _, v = self.fused(None, logits_out=self.logits, packed=self._packed, n_boards=self.e.n_slots)
             self.values = v.view(-1)  # handed to expand_backup as is (no copy)
             return

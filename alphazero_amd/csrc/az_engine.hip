@@ -977,8 +977,9 @@ int az_begin_search(az_engine *e, void *stream) {
 }
 
 int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf_dev, const void **list_dev,
-                    const void **count_dev) {
+                    const void **count_dev, const void **flags_dev) {
   if (!e) return AZ_EINVAL;
+  if (flags_dev) *flags_dev = e->v.evalFlag;
   if (ring_dev) *ring_dev = e->v.leafRing;
   if (leaf_dev) *leaf_dev = e->v.leaf;
   if (list_dev) *list_dev = e->v.evalList;

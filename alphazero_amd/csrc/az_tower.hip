@@ -324,7 +324,8 @@ __device__ __forceinline__ void glds4(const void *g_lane, void *lds_base) {
 template <int N, int BPW, int NPT, int ST>
 __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
                                                const int4 *__restrict__ leafrec, const int32_t *__restrict__ list,
-                                               const int32_t *__restrict__ count, int G, const char *__restrict__ w0,
+                                               const int32_t *__restrict__ count, const uint8_t *__restrict__ flags, int G,
+                                               const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
                                                uint16_t *__restrict__ feat, int FS, unsigned int *tickets) {
@@ -378,8 +379,16 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   auto lookup = [&]() {  // step 2 (uses the ticket)
     if (wave != 0) return;
     tk_next = __builtin_amdgcn_readfirstlane(tk_draw);
-    const int ci = tk_next * BPW + lane;
-    sl_next = (tk_next < ngroups && lane < BPW && ci < nb_total) ? (list != nullptr ? list[ci] : ci) : -1;
+    for (;;) {
+      const int ci = tk_next * BPW + lane;
+      sl_next = (tk_next < ngroups && lane < BPW && ci < nb_total) ? (list != nullptr ? list[ci] : ci) : -1;
+      if (flags == nullptr || tk_next >= ngroups) break;
+      // flag mode: a group is BPW consecutive slots, of which only the flagged ones are evaluated; a group without any
+      // (7 % of the single-board groups: terminal leaves) costs one more draw, waited for on the spot
+      if (sl_next >= 0 && flags[sl_next] == 0) sl_next = -1;
+      if (__ballot(sl_next >= 0) != 0ull) break;
+      tk_next = __builtin_amdgcn_readfirstlane(lane == 0 ? (int)atomicAdd(&tickets[0], 1u) : 0);
+    }
   };
   auto fetch = [&](int which) {  // step 3 (uses the slots): slots + ticket by ds_write, ring words + players by LDS-DMA
     if (wave != 0) return;
@@ -736,8 +745,8 @@ int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16
 
 int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
                      const void *packed_ring_dev, const void *packed_leaf_dev, const void *list_dev,
-                     const void *count_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
-                     const float *headb_dev, void *feat_bf16_dev, int32_t feat_stride, void *stream) {
+                     const void *count_dev, const void *flags_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev,
+                     const float *headw_dev, const float *headb_dev, void *feat_bf16_dev, int32_t feat_stride, void *stream) {
   using namespace aztower;
   if ((!x_bf16_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !feat_bf16_dev ||
       (n_conv_layers > 0 && !wl_dev)) { g_tower_err = "null argument"; return AZ_EINVAL; }
@@ -766,9 +775,10 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
     const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * AZ_TOWER_WAVES_PER_SIMD;
     const int grid = groups < cap ? groups : cap;
     const bool use_list = !x_bf16_dev && list_dev && count_dev;
+    const bool use_flags = !x_bf16_dev && !use_list && flags_dev;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
                        (const int4 *)packed_leaf_dev, (const int32_t *)(use_list ? list_dev : nullptr),
-                       (const int32_t *)(use_list ? count_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
+                       (const int32_t *)(use_list ? count_dev : nullptr), (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
                        n_conv_layers, headw_dev, headb_dev, (uint16_t *)feat_bf16_dev, (int)feat_stride, tickets);
     return AZ_OK;
   };

@@ -78,12 +78,12 @@ def load_library() -> C.CDLL:
     lib.az_reset_stats.argtypes = [vp, vp]
     lib.az_eval_hash.argtypes = [vp, vp, C.c_float, vp, vp, vp]
     lib.az_augment_samples.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
-    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]
+    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]
     lib.az_heads_forward.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
     lib.az_heads_feat_stride.argtypes = [C.c_int32]
     lib.az_heads_feat_stride.restype = C.c_int32
     lib.az_compact_leaves.argtypes = [vp, vp]
-    lib.az_leaf_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.az_leaf_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
     for name in EXPORTS:
@@ -207,10 +207,10 @@ class Engine:
 
     def leaf_buffers(self):
         """device addresses (ints) of the packed leaf batch: (ring u32 (G,8,SW), leaf records int32 (G,4),
-        list of slots to evaluate i32 (G), their count i32)"""
-        ring, leaf, lst, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        self._ck(self.lib.az_leaf_buffers(self._h, C.byref(ring), C.byref(leaf), C.byref(lst), C.byref(cnt)))
-        return ring.value, leaf.value, lst.value, cnt.value
+        list of slots to evaluate i32 (G), their count i32, per-slot needs-the-network flags u8 (G))"""
+        ring, leaf, lst, cnt, flg = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.az_leaf_buffers(self._h, C.byref(ring), C.byref(leaf), C.byref(lst), C.byref(cnt), C.byref(flg)))
+        return ring.value, leaf.value, lst.value, cnt.value, flg.value
 
     def compact_leaves(self):
         """fill the list/count of leaf_buffers() for the batch of the last select_gather"""

@@ -108,14 +108,15 @@ class FusedTowerEvaluator:
         self.b2 = float(v2.bias.detach().float().reshape(-1)[0])
 
     def __call__(self, x: torch.Tensor | None, logits_out: torch.Tensor | None = None, packed=None, n_boards: int = 0):
-        """x: contiguous (B,9,N,N) bf16 batch, or None with packed = Engine.leaf_buffers() (ring, leaf[, list, count])
-        and n_boards = the engine's slot count: the packed leaf batch is read straight from the engine and, when the
-        list is given, only the slots whose leaf needs the network are evaluated (other output rows keep old data)."""
+        """x: contiguous (B,9,N,N) bf16 batch, or None with packed = (ring, leaf[, list, count[, flags]]) from
+        Engine.leaf_buffers() and n_boards = the engine's slot count: the packed leaf batch is read straight from the
+        engine; with list + count (after Engine.compact_leaves()) or, when those are None, with the flags, only the slots
+        whose leaf needs the network are evaluated (other output rows keep old data)."""
         if x is not None:
             if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
                 raise EngineError("FusedTowerEvaluator expects a contiguous (B,9,N,N) bf16 batch on the model's GPU")
             B = x.shape[0]
-            ring_p = leaf_p = list_p = count_p = None
+            ring_p = leaf_p = list_p = count_p = flags_p = None
         else:
             if packed is None or n_boards < 1:
                 raise EngineError("FusedTowerEvaluator: give either x or packed=(ring, leaf) with n_boards")
@@ -123,6 +124,7 @@ class FusedTowerEvaluator:
             ring_p, leaf_p = C.c_void_p(packed[0]), C.c_void_p(packed[1])
             list_p = C.c_void_p(packed[2]) if len(packed) > 3 and packed[2] else None
             count_p = C.c_void_p(packed[3]) if len(packed) > 3 and packed[3] else None
+            flags_p = C.c_void_p(packed[4]) if len(packed) > 4 and packed[4] else None
         if B not in self._buf:  # zeroed once: the kernels never write the pad columns, and the heads multiply them by zero weights
             self._buf[B] = (torch.zeros(B, self.feat_stride, dtype=torch.bfloat16, device=self.device),
                             torch.empty(B, self.n2, device=self.device), torch.empty(B, device=self.device))
@@ -136,7 +138,7 @@ class FusedTowerEvaluator:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         rc = self.lib.az_tower_forward(self.board, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
-                                       list_p, count_p, P(self.w0), P(self.wl), P(self.bias),
+                                       list_p, count_p, flags_p, P(self.w0), P(self.wl), P(self.bias),
                                        P(self.headw), P(self.headb), P(feat), self.feat_stride, st)
         if rc != 0:
             raise EngineError(f"az_tower_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")

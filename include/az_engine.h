@@ -110,10 +110,12 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream);
  * leaf_dev -> int32 x4 per slot {depth, kind (0 = needs the network, 1 = terminal), value bits, player};
  * list_dev -> i32 (n_slots): the slots whose leaf needs the network, ascending, and count_dev -> i32: how many
  * (terminal leaves, which the reference re-evaluates by rule on every revisit, are absent); both are filled by
- * az_compact_leaves, to be called after az_select_gather when they are wanted.
+ * az_compact_leaves, to be called after az_select_gather when they are wanted;
+ * flags_dev -> u8 (n_slots): 1 where the slot's leaf needs the network (always filled; what az_tower_forward scans
+ * when it is given no list).
  * Consumed by az_tower_forward; ~8x fewer bytes than the dense planes.  Any out pointer may be NULL. */
 int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf_dev, const void **list_dev,
-                    const void **count_dev);
+                    const void **count_dev, const void **flags_dev);
 int az_compact_leaves(az_engine *e, void *stream);
 
 /* The rest of that simulation: _get_prior :180-192 (softmax, Dirichlet mix at the root, legal mask,
@@ -191,7 +193,8 @@ int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *log
  *   x_bf16_dev (n_boards, 9, N, N) bf16 = the batch az_select_gather writes with AZ_NN_BF16, or NULL to read
  *   the packed leaf batch instead (packed_ring_dev / packed_leaf_dev from az_leaf_buffers of a gomoku engine
  *   of the same board size; both may be NULL when x_bf16_dev is given); with list_dev / count_dev (same call,
- *   or NULL) only the listed slots are evaluated and only their rows of pfeat / vfeat are written;
+ *   or NULL) only the listed slots are evaluated and only their rows of feat are written; with flags_dev (same
+ *   call; used when no list is given) only the slots whose flag byte is non-zero -- no compaction launch needed;
  *   w0_dev [9][1][2][64][8] bf16, wl_dev [n_conv_layers][9][4][2][64][8] bf16 ([tap][k-step][k-half][co][8 ci]);
  *   bias_dev [1+n_conv_layers][64] f32; headw_dev [3][64] f32, headb_dev [3] f32 (policy, value0, value1);
  *   feat_bf16_dev (n_boards, feat_stride) bf16 out: the inputs of the heads' Linear layers, row layout
@@ -201,8 +204,8 @@ int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *log
  *   library (16 pairs per GPU, rotated per launch): at most 16 launches may be in flight on one GPU. */
 int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
                      const void *packed_ring_dev, const void *packed_leaf_dev, const void *list_dev,
-                     const void *count_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
-                     const float *headb_dev, void *feat_bf16_dev, int32_t feat_stride, void *stream);
+                     const void *count_dev, const void *flags_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev,
+                     const float *headw_dev, const float *headb_dev, void *feat_bf16_dev, int32_t feat_stride, void *stream);
 
 /* The heads' Linear layers of the same network family (examples/gomoku/model.py:69-72, 84-90) for the whole batch:
  *   logits = feat[:, :N*N] @ Wp^T + bp;   value = tanh(relu(feat[:, KP:KP+2N*N] @ W1^T + b1) @ w2 + b2)

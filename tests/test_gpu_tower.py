@@ -92,7 +92,7 @@ def test_packed_leaf_batch_equals_dense_planes(board):
     p1, v1 = ev(nn)
     p1, v1 = p1.clone(), v1.clone()
     eng.compact_leaves()
-    ring, leaf, lst, cnt = eng.leaf_buffers()
+    ring, leaf, lst, cnt, flg = eng.leaf_buffers()
     p2, v2 = ev(None, packed=(ring, leaf), n_boards=G)          # packed, every slot
     eng.check()
     assert torch.equal(p1, p2) and torch.equal(v1, v2)
@@ -103,3 +103,9 @@ def test_packed_leaf_batch_equals_dense_planes(board):
     touched = pfeat[:, 0] >= 0
     assert 0 < n_eval <= G and int(touched.sum()) == n_eval
     assert torch.equal(p3[touched], p1[touched]) and torch.equal(v3[touched], v1[touched])
+    for t in ev._buf[G]:
+        t.fill_(-1.0)
+    p4, v4 = ev(None, packed=(ring, leaf, None, None, flg), n_boards=G)  # packed + flags: the same set, no compaction launch
+    touched4 = ev._buf[G][0][:, 0] >= 0
+    assert torch.equal(touched4, touched)
+    assert torch.equal(p4[touched], p1[touched]) and torch.equal(v4[touched], v1[touched])
