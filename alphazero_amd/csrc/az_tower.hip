@@ -91,7 +91,7 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 #define STAMP(k) do { } while (0)
 #endif
 #ifndef AZ_TOWER_ABLATE
-#define AZ_TOWER_ABLATE 0  // 0 = product; 1 / 2 = timing diagnostics only (wrong results)
+#define AZ_TOWER_ABLATE 0  // 0 = product; 1 .. 4 = timing diagnostics only (wrong results)
 #endif
 // 15x15 geometry: boards per workgroup / cell tiles per wave / taps per stage.  (1,2,3): 2x2 accumulator tiles,
 // one kernel row of weights per barrier.  (2,4,1): 4x2 accumulator tiles (A fragments reused over 4 cell tiles:
@@ -103,9 +103,6 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 #endif
 #ifndef AZ_TOWER9_ST
 #define AZ_TOWER9_ST 1  // 9x9 (3 boards per workgroup): per-tap staging keeps two workgroups within a CU's 160 KiB of LDS
-#endif
-#ifndef AZ_TOWER_PREFETCH
-#define AZ_TOWER_PREFETCH 1  // k-steps (of 2 + NPT fragment reads) issued ahead of the MFMAs that consume them
 #endif
 #ifndef AZ_TOWER_WAVES_PER_SIMD
 #define AZ_TOWER_WAVES_PER_SIMD 2
