@@ -57,15 +57,16 @@ __device__ __forceinline__ int fresh(int v) { asm volatile("" : "+v"(v)); return
 __device__ __forceinline__ int act_addr(int p, int chunk) { return p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4); }
 
 // N = board, BPW = boards per workgroup, NPT = 32-cell tiles per wave (4 waves), ST = taps staged per barrier
-template <int N, int BPW, int NPT, int ST_>
+template <int N, int BPW, int NPT, int ST_, int NW_ = 4>
 struct Geo {
+  static constexpr int NW = NW_;  // waves per workgroup
   static constexpr int NV = N * N, NVT = BPW * NV, ST = ST_;
   static constexpr int ZERO_OFF = NVT * 128;       // one all-zero 128-byte row: where taps off the board read
   static constexpr int ACT_BYTES = NVT * 128 + 128;
   static constexpr int STAGE_BYTES = ST * TAP_BYTES;
   static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = BPW * 8 * SWB;  // packed input words per group
   static constexpr int RG_BYTES = ((RGW * 4 + 8 * BPW + 4 + 15) / 16) * 16;     // ring words, BPW players, BPW slots, the group's ticket
-  static_assert(NVT <= 4 * NPT * 32, "4 waves x NPT tiles of 32 cells");
+  static_assert(NVT <= NW * NPT * 32, "NW waves x NPT tiles of 32 cells");
   static_assert(NPT == 2 || NPT == 4, "conv_layer counts its fragment reads for 2 or 4 cell tiles per wave");
   static_assert(RGW * 4 <= 64 * 16, "one 16-byte LDS-DMA per lane moves the packed input");
   static size_t lds_bytes(int n_layers) {
@@ -101,6 +102,9 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 #define AZ_TOWER15_NPT 2
 #define AZ_TOWER15_ST 3
 #endif
+#ifndef AZ_TOWER15_NW
+#define AZ_TOWER15_NW 4  // waves per workgroup (8 with BPW 2: two boards share one weight stream, one workgroup per CU)
+#endif
 #ifndef AZ_TOWER9_ST
 #define AZ_TOWER9_ST 1  // 9x9 (3 boards per workgroup): per-tap staging keeps two workgroups within a CU's 160 KiB of LDS
 #endif
@@ -118,9 +122,9 @@ __device__ __forceinline__ void glds16o(const char *g_lane, char *lds_base) {
 // stage ST taps of weights (NCHUNK = ST*KS*2 KiB, [tap][ks][half][co][8] bf16, contiguous in global memory and in the
 // LDS buffer alike): 1 KiB per wave-instruction, each wave a run of consecutive pieces, four pieces per address
 // pair through the instruction's immediate offset -- a handful of instructions per stage, issued under the MFMAs
-template <int KS, int ST>
+template <int KS, int ST, int NW>
 __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave, int lane) {
-  constexpr int NCHUNK = ST * KS * 2, PW = (NCHUNK + 3) / 4;
+  constexpr int NCHUNK = ST * KS * 2, PW = (NCHUNK + NW - 1) / NW;
 #if AZ_TOWER_ABLATE == 3  // diagnostic build: no weight streaming at all
   return;
 #endif
@@ -152,7 +156,7 @@ __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave,
 // off the board); the k-step then only XORs (ks << 5) into it.
 // Fragment reads are inline asm with hand-counted waits: hipcc's own ds_read + MFMA schedule here reads each
 // fragment just before its MFMA and waits lgkmcnt(0) every time (one exposed LDS round trip per two MFMAs).
-template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST>
+template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST, int NW>
 __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext,
                                            int tid, int lane, const int (&pp)[NPT], const uint32_t (&vm)[NPT],
                                            f32x16 (&acc)[NPT][2], unsigned long long *twait = nullptr) {
@@ -230,8 +234,8 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
       __builtin_amdgcn_sched_barrier(0);
       if (i == 0) {  // the DMA of the next stage's weights: issued under this stage's MFMAs
         char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
-        if (sg < NSTAGE - 1) stage_w<KS, ST>(wg + (sg + 1) * ST * TB, wn, wave, lane);
-        else if (wnext != nullptr) stage_w<KSN, ST>(wnext, wn, wave, lane);
+        if (sg < NSTAGE - 1) stage_w<KS, ST, NW>(wg + (sg + 1) * ST * TB, wn, wave, lane);
+        else if (wnext != nullptr) stage_w<KSN, ST, NW>(wnext, wn, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -318,16 +322,16 @@ __device__ __forceinline__ void glds4(const void *g_lane, void *lds_base) {
 // w0: [9][1][2][64][8] bf16 (first conv, 9 input channels padded to 16).  wl: [L][9][4][2][64][8] bf16.
 // bias: [1+L][64] f32.  headw: [3][64] f32 (policy, value0, value1), headb: [3].
 // feat: (G, FS) bf16 = the inputs of the heads' Linear layers (layout: see the heads' epilogue and k_heads).
-template <int N, int BPW, int NPT, int ST>
-__global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
+template <int N, int BPW, int NPT, int ST, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
                                                const int4 *__restrict__ leafrec, const int32_t *__restrict__ list,
                                                const int32_t *__restrict__ count, const uint8_t *__restrict__ flags, int G,
                                                const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
                                                uint16_t *__restrict__ feat, int FS, unsigned int *tickets) {
-  using Q = Geo<N, BPW, NPT, ST>;
-  constexpr int WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RG_STRIDE = Q::RG_BYTES, STAGE_BYTES = Q::STAGE_BYTES;
+  using Q = Geo<N, BPW, NPT, ST, NW>;
+  constexpr int WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RG_STRIDE = Q::RG_BYTES, STAGE_BYTES = Q::STAGE_BYTES, NTH = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *act = smem;
   char *wbuf = smem + Q::ACT_BYTES;
@@ -336,9 +340,9 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   float *bl = (float *)(rgb + 2 * RG_STRIDE);     // 3 x 64 biases: the running layer's, the next one's (DMA'd under this layer's conv), the last one's
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  for (int i = tid; i < Q::ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero slot
-  for (int i = tid; i < 3 * CH + 3; i += 256) hw[i] = i < 3 * CH ? headw[i] : headb[i - 3 * CH];
-  for (int i = tid; i < CH; i += 256) bl[i] = bias[i];  // the stem's; every later layer's row arrives by LDS-DMA, one layer ahead
+  for (int i = tid; i < Q::ACT_BYTES / 16; i += NTH) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero slot
+  for (int i = tid; i < 3 * CH + 3; i += NTH) hw[i] = i < 3 * CH ? headw[i] : headb[i - 3 * CH];
+  for (int i = tid; i < CH; i += NTH) bl[i] = bias[i];  // the stem's; every later layer's row arrives by LDS-DMA, one layer ahead
 
   // this lane's NPT cells (B-operand column / accumulator column): tile = NPT*wave + pt
   int pp[NPT];
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
   };
   auto bias_step = [&]() { bslot = bslot == 2 ? 0 : bslot + 1; };
   // prologue: the stem's first weight stage and the first group's input
-  stage_w<1, ST>(w0, wbuf, wave, lane);
+  stage_w<1, ST, NW>(w0, wbuf, wave, lane);
   draw();
   lookup();
   fetch(0);
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     draw();  // the next group's ticket: on its way while this group's input is expanded and the stem runs
     // ---- input -> act[cell][0..15] (channels 9..15 zero): the NCHW bf16 planes, or the packed leaf batch
     // (8 bitboard states per board + the player to move), expanded here
-    for (int m = fresh(tid); m < Q::NVT; m += 256) {
+    for (int m = fresh(tid); m < Q::NVT; m += NTH) {
       const int b = m / Q::NV, cell = m % Q::NV, g = slots[b];
       uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (g >= 0) {
@@ -472,8 +476,8 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
     init_acc<false, NPT>(bl + bslot * CH, lane, acc, res);
     if (L > 0) bias_ahead(1);
     else bias_ahead(0);  // (the next group's stem; harmless when there is none)
-    if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
-    else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, w0, w0, tid, lane, pp, vm, acc);
+    if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
+    else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, w0, w0, tid, lane, pp, vm, acc);
     STAMP(2);
     bias_step();
     epilogue<NPT>(act, lane, pp, ok, acc);
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
       init_acc<false, NPT>(bl + bslot * CH, lane, acc, res);
       bias_ahead(2 + l);
       STAMP(sk + 0);
-      conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
+      conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
                                        lane, pp, vm, acc, twp);
       STAMP(sk + 1);
       bias_step();
@@ -514,10 +518,10 @@ __global__ __launch_bounds__(256, AZ_TOWER_WAVES_PER_SIMD) void k_tower(const ui
       else bias_ahead(0);
       STAMP(sk + 3);
       if (l + 2 < L)
-        conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
+        conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
                                          tid, lane, pp, vm, acc, twp);
       else  // last layer of this board: prefetch the next board's stem weights
-        conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, w0, tid, lane,
+        conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, w0, tid, lane,
                                          pp, vm, acc, twp);
       STAMP(sk + 4);
       bias_step();
@@ -766,14 +770,14 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
     }
     tickets = g_ticket_base[dev] + 2 * (g_ticket_seq[dev]++ % AZ_TOWER_TICKET_PAIRS);
   }
-  auto launch = [&](auto kern, size_t lds, int bpw) -> int {
+  auto launch = [&](auto kern, size_t lds, int bpw, int nw) -> int {
     if (lds > 160 * 1024) { g_tower_err = "tower geometry exceeds the CU's LDS"; return AZ_EINVAL; }
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * AZ_TOWER_WAVES_PER_SIMD;
+    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * (nw == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1);  // workgroups that fit the chip
     const int grid = groups < cap ? groups : cap;
     const bool use_list = !x_bf16_dev && list_dev && count_dev;
     const bool use_flags = !x_bf16_dev && !use_list && flags_dev;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
                        (const int4 *)packed_leaf_dev, (const int32_t *)(use_list ? list_dev : nullptr),
                        (const int32_t *)(use_list ? count_dev : nullptr), (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
                        n_conv_layers, headw_dev, headb_dev, (uint16_t *)feat_bf16_dev, (int)feat_stride, tickets);
@@ -781,10 +785,10 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
   };
   int rc;
   if (board_size == 15) {
-    rc = launch(k_tower<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST>,
-                Geo<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST>::lds_bytes(n_conv_layers), AZ_TOWER15_BPW);
+    rc = launch(k_tower<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, AZ_TOWER15_NW>,
+                Geo<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, AZ_TOWER15_NW>::lds_bytes(n_conv_layers), AZ_TOWER15_BPW, AZ_TOWER15_NW);
   } else if (board_size == 9) {
-    rc = launch(k_tower<9, 3, 2, AZ_TOWER9_ST>, Geo<9, 3, 2, AZ_TOWER9_ST>::lds_bytes(n_conv_layers), 3);
+    rc = launch(k_tower<9, 3, 2, AZ_TOWER9_ST, 4>, Geo<9, 3, 2, AZ_TOWER9_ST, 4>::lds_bytes(n_conv_layers), 3, 4);
   } else {
     g_tower_err = "board_size must be 9 or 15";
     return AZ_EINVAL;
