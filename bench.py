@@ -363,7 +363,7 @@ def main():
                        "peak": 2500.0, "unit": "TFLOP/s", "frac": (fl / (nn_ms * 1e-3) / 1e12 / 2500.0) if nn_ms else 0.0,
                        "flops_per_eval": model.flops_per_eval(), "boards_per_batch": evals_per_launch,
                        "share_of_step": nn_ms / max(nn_ms + tree_ms, 1e-9),
-                       "implementation": "az_tower.hip fused bf16 MFMA tower + torch head linears" if args.evaluator == "fused"
+                       "implementation": "az_tower.hip: k_tower (fused bf16 MFMA conv tower) + k_heads (MFMA head linears)" if args.evaluator == "fused"
                        else "PyTorch/MIOpen module forward"}
             if args.evaluator == "fused" and ev_tower:
                 # the dominant kernel of the step: the fused conv tower (MFMA bound).  Algorithmic flops = the convolutions'
