@@ -22,7 +22,8 @@
 //   the 4 waves, issued under the running stage's MFMAs; fragment reads software pipelined by hand (inline-asm
 //   ds_read_b128 + counted lgkmcnt waits).  The layer is computed in place (outputs stay in accumulators until
 //   every wave has finished reading the input, then overwrite it); the residual is kept in registers; the
-//   accumulators start at bias (+ residual), the epilogue is ReLU + pack + store.
+//   accumulators start at bias (+ residual), the epilogue is ReLU + pack + store.  The stem (18 KiB of weights) is one
+//   stage without inner barriers; the heads' 1x1 convs are computed from the last layer's f32 accumulators on the VALU.
 //   Boards are handed out by a ticket counter (see the kernel); biases and the next board's packed input
 //   arrive by LDS-DMA ahead of their use.
 #include <hip/hip_runtime.h>
@@ -37,6 +38,7 @@ namespace aztower {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int CH = 64;          // trunk width
 constexpr int TAP_BYTES = 8192; // one tap of a 64->64 layer: [ks 4][half 2][co 64][8] bf16
@@ -156,12 +158,15 @@ __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave,
 // off the board); the k-step then only XORs (ks << 5) into it.
 // Fragment reads are inline asm with hand-counted waits: hipcc's own ds_read + MFMA schedule here reads each
 // fragment just before its MFMA and waits lgkmcnt(0) every time (one exposed LDS round trip per two MFMAs).
-template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST, int NW>
+// BS = bytes between the two weight buffers; STN = taps per stage of the NEXT layer (the stem, 18 KiB of weights in all,
+// runs as one stage without any intermediate barrier when a buffer holds it).
+template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST, int NW, int STN, int BS>
 __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext,
                                            int tid, int lane, const int (&pp)[NPT], const uint32_t (&vm)[NPT],
                                            f32x16 (&acc)[NPT][2], unsigned long long *twait = nullptr) {
   constexpr int TB = KS * 2048;  // bytes per tap
-  constexpr int NSTAGE = 9 / ST, STAGE_BYTES = ST * TAP_BYTES, NK = ST * KS;
+  constexpr int NSTAGE = 9 / ST, STAGE_BYTES = BS, NK = ST * KS;
+  static_assert(ST * TB <= BS && STN * KSN * 2048 <= BS, "a stage fits its buffer");
   constexpr bool XPF = (NK % 2 == 0) && NSTAGE > 1;  // cross-barrier prefetch needs the last k-step in register set 1
   const int h = lane >> 5, r = lane & 31, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
@@ -235,7 +240,7 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
       if (i == 0) {  // the DMA of the next stage's weights: issued under this stage's MFMAs
         char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
         if (sg < NSTAGE - 1) stage_w<KS, ST, NW>(wg + (sg + 1) * ST * TB, wn, wave, lane);
-        else if (wnext != nullptr) stage_w<KSN, ST, NW>(wnext, wn, wave, lane);
+        else if (wnext != nullptr) stage_w<KSN, STN, NW>(wnext, wn, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -257,7 +262,6 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
   buf = (buf + NSTAGE) & 1;
 }
 
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) short i16x2;
 
@@ -294,21 +298,83 @@ __device__ __forceinline__ void init_acc(const float *bias, int lane, f32x16 (&a
       }
 }
 
-// ReLU, bf16, written back in place
+// ReLU, bf16, written back in place.  (Keeping the packed values in registers as the next block's residual instead of
+// reading them back was tried: 32 more live VGPRs across the epilogue, spills, slower.)
 template <int NPT>
 __device__ __forceinline__ void epilogue(char *act, int lane, const int (&pp)[NPT], const bool (&ok)[NPT],
                                          const f32x16 (&acc)[NPT][2]) {
   const int h = fresh(lane) >> 5;
 #pragma unroll
   for (int pt = 0; pt < NPT; ++pt) {
-    if (!ok[pt]) continue;
     const int pe = fresh(pp[pt]);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(uint2 *)(act + act_addr(pe, ct * 4 + q) + 8 * h) =
-            make_uint2(pack_relu(acc[pt][ct][4 * q + 0], acc[pt][ct][4 * q + 1]), pack_relu(acc[pt][ct][4 * q + 2], acc[pt][ct][4 * q + 3]));
+      for (int q = 0; q < 4; ++q) {
+        const uint2 v = make_uint2(pack_relu(acc[pt][ct][4 * q + 0], acc[pt][ct][4 * q + 1]), pack_relu(acc[pt][ct][4 * q + 2], acc[pt][ct][4 * q + 3]));
+        if (ok[pt]) *(uint2 *)(act + act_addr(pe, ct * 4 + q) + 8 * h) = v;
+      }
+  }
+}
+
+// heads' 1x1 convs from the accumulators of the last trunk layer (bias and residual already in them, ReLU applied here in f32).
+// hw: [3][64] filters + [3] biases, f32, in LDS.  acc[pt][ct][4q + j] = channel ct*32 + q*8 + (lane>>5)*4 + j of cell pp[pt].
+template <int NPT, int NV>
+__device__ __forceinline__ void heads_from_acc(const float *hw, int lane_, const int (&pp)[NPT], const bool (&ok)[NPT],
+                                               const int *slots, const f32x16 (&acc)[NPT][2], uint16_t *feat, int FS) {
+  const int lane = fresh(lane_), h = lane >> 5;
+  f32x2 hs[NPT][3];
+#pragma unroll
+  for (int pt = 0; pt < NPT; ++pt) hs[pt][0] = hs[pt][1] = hs[pt][2] = (f32x2){0.0f, 0.0f};
+  // every LDS operand of the head is requested up front (one round trip: under the partner workgroup's fragment traffic a
+  // dependent LDS access costs several hundred cycles); packed f32 FMAs; ReLU as a signed integer max (a negative
+  // float is a negative int)
+  float4 wv[2][4][3];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wv[ct][q][k] = *(const float4 *)(hw + k * CH + ct * 32 + q * 8 + h * 4);
+  const float hb0 = hw[3 * CH + 0], hb1 = hw[3 * CH + 1], hb2 = hw[3 * CH + 2];
+  int gs[NPT];
+#pragma unroll
+  for (int pt = 0; pt < NPT; ++pt) gs[pt] = slots[pp[pt] / NV];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+        f32x2 va, vb;
+        va[0] = __int_as_float(max(__float_as_int(acc[pt][ct][4 * q + 0]), 0));
+        va[1] = __int_as_float(max(__float_as_int(acc[pt][ct][4 * q + 1]), 0));
+        vb[0] = __int_as_float(max(__float_as_int(acc[pt][ct][4 * q + 2]), 0));
+        vb[1] = __int_as_float(max(__float_as_int(acc[pt][ct][4 * q + 3]), 0));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          hs[pt][k] = __builtin_elementwise_fma(va, (f32x2){wv[ct][q][k].x, wv[ct][q][k].y}, hs[pt][k]);
+          hs[pt][k] = __builtin_elementwise_fma(vb, (f32x2){wv[ct][q][k].z, wv[ct][q][k].w}, hs[pt][k]);
+        }
+      }
+  constexpr int KP = (NV + 15) / 16 * 16;
+#pragma unroll
+  for (int pt = 0; pt < NPT; ++pt) {
+    float t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // own half + the other half-wave's: v_permlane32_swap (no LDS round trip)
+      const float own = hs[pt][k][0] + hs[pt][k][1];
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
+      t[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    if ((pt & 1) != h || !ok[pt]) continue;  // even tiles are written by the lower half-wave, odd ones by the upper
+    const int cell = fresh(pp[pt]) % NV, g = gs[pt];
+    if (g < 0) continue;
+    // the heads' Linear inputs, bf16: [policy NV | pad to 16 | value0 NV | value1 NV | pad] (az_heads_forward reads it)
+    uint16_t *fr = feat + (size_t)g * FS;
+    fr[cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(t[0] + hb0, 0.0f));
+    fr[KP + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(t[1] + hb1, 0.0f));
+    fr[KP + NV + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(t[2] + hb2, 0.0f));
   }
 }
 
@@ -332,6 +398,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
                                                uint16_t *__restrict__ feat, int FS, unsigned int *tickets) {
   using Q = Geo<N, BPW, NPT, ST, NW>;
   constexpr int WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RG_STRIDE = Q::RG_BYTES, STAGE_BYTES = Q::STAGE_BYTES, NTH = NW * 64;
+  // the stem's taps per stage: all nine (18 KiB, no barrier inside the layer) when a weight buffer holds them
+#ifdef AZ_TOWER_STEM_ST
+  constexpr int ST0 = AZ_TOWER_STEM_ST;
+#else
+  constexpr int ST0 = 9 * 2048 <= STAGE_BYTES ? 9 : (3 * 2048 <= STAGE_BYTES ? 3 : 1);
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *act = smem;
   char *wbuf = smem + Q::ACT_BYTES;
@@ -415,7 +487,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
   };
   auto bias_step = [&]() { bslot = bslot == 2 ? 0 : bslot + 1; };
   // prologue: the stem's first weight stage and the first group's input
-  stage_w<1, ST, NW>(w0, wbuf, wave, lane);
+  stage_w<1, ST0, NW>(w0, wbuf, wave, lane);
   draw();
   lookup();
   fetch(0);
@@ -476,25 +548,29 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
     init_acc<false, NPT>(bl + bslot * CH, lane, acc, res);
     if (L > 0) bias_ahead(1);
     else bias_ahead(0);  // (the next group's stem; harmless when there is none)
-    if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
-    else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, w0, w0, tid, lane, pp, vm, acc);
+    if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST0, NW, ST, STAGE_BYTES>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
+    else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST0, NW, ST0, STAGE_BYTES>(act, wbuf, buf, w0, w0, tid, lane, pp, vm, acc);
     STAMP(2);
     bias_step();
-    epilogue<NPT>(act, lane, pp, ok, acc);
-    __syncthreads();
+    if (L > 0) {
+      epilogue<NPT>(act, lane, pp, ok, acc);
+      __syncthreads();
+    }
     STAMP(3);
     lookup();  // the ticket drawn at the top of the loop has long arrived
     if (L == 0) fetch(inb);
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
-      const int h = fresh(lane) >> 5;
+      {  // res = this block's input
+        const int h = fresh(lane) >> 5;
 #pragma unroll
-      for (int pt = 0; pt < NPT; ++pt) {
-        const int pe = fresh(pp[pt]);
+        for (int pt = 0; pt < NPT; ++pt) {
+          const int pe = fresh(pp[pt]);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+          for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pe, ct * 4 + q) + 8 * h);
+            for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pe, ct * 4 + q) + 8 * h);
+        }
       }
 #if AZ_TOWER_STAMP
       const int sk = 4 + (l & 2) * 4;
@@ -505,7 +581,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
       init_acc<false, NPT>(bl + bslot * CH, lane, acc, res);
       bias_ahead(2 + l);
       STAMP(sk + 0);
-      conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
+      conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST, NW, ST, STAGE_BYTES>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
                                        lane, pp, vm, acc, twp);
       STAMP(sk + 1);
       bias_step();
@@ -518,64 +594,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
       else bias_ahead(0);
       STAMP(sk + 3);
       if (l + 2 < L)
-        conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
+        conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST, NW, ST, STAGE_BYTES>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
                                          tid, lane, pp, vm, acc, twp);
       else  // last layer of this board: prefetch the next board's stem weights
-        conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST, NW>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, w0, tid, lane,
+        conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST, NW, ST0, STAGE_BYTES>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, w0, tid, lane,
                                          pp, vm, acc, twp);
       STAMP(sk + 4);
       bias_step();
-      epilogue<NPT>(act, lane, pp, ok, acc);
-      __syncthreads();
+      if (l + 2 < L) {  // (the last layer's output stays in the accumulators for the heads)
+        epilogue<NPT>(act, lane, pp, ok, acc);
+        __syncthreads();
+      }
       STAMP(sk + 5);
 #if AZ_TOWER_STAMP
       if (stamp_on) tsv[sk + 6] = tw;
 #endif
     }
-    // ---- heads: the three 1x1 convs (+folded BN) + ReLU as one more implicit GEMM: rows 0..2 of a 32-row A tile
-    // are the head filters (built here from the f32 table in LDS, bf16), the B fragments are the centre tap of the
-    // trunk output; lanes 0..31 end up with their cell's three outputs in accumulator registers 0..2
-    {
-      const int hl = fresh(lane), h = hl >> 5, r = hl & 31;
-      f32x16 hacc[NPT];
-#pragma unroll
-      for (int pt = 0; pt < NPT; ++pt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) hacc[pt][i] = 0.0f;
-      const int pe0 = fresh(pp[0]);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 a;
-        const float *wr = hw + (r < 3 ? r : 0) * CH + ks * 16 + 8 * h;
-        const float4 w0v = *(const float4 *)wr, w1v = *(const float4 *)(wr + 4);
-        const float m = r < 3 ? 1.0f : 0.0f;
-        a[0] = (__bf16)(w0v.x * m); a[1] = (__bf16)(w0v.y * m); a[2] = (__bf16)(w0v.z * m); a[3] = (__bf16)(w0v.w * m);
-        a[4] = (__bf16)(w1v.x * m); a[5] = (__bf16)(w1v.y * m); a[6] = (__bf16)(w1v.z * m); a[7] = (__bf16)(w1v.w * m);
-#pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) {
-          const int pe = pt == 0 ? pe0 : fresh(pp[pt]);
-          const bf16x8 b = *(const bf16x8 *)(act + act_addr(pe, ks * 2 + h));
-          hacc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, hacc[pt], 0, 0, 0);
-        }
-      }
-      if (h == 0) {
-#pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) {
-          if (!ok[pt]) continue;
-          const int m = fresh(pp[pt]), b = m / Q::NV, cell = m % Q::NV, g = slots[b];
-          if (g < 0) continue;
-          // the heads' Linear inputs, bf16: [policy NV | pad to 16 | value0 NV | value1 NV | pad] (az_heads_forward reads it)
-          constexpr int KP = (Q::NV + 15) / 16 * 16;
-          uint16_t *fr = feat + (size_t)g * FS;
-          fr[cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(hacc[pt][0] + hw[3 * CH + 0], 0.0f));
-          fr[KP + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(hacc[pt][1] + hw[3 * CH + 1], 0.0f));
-          fr[KP + Q::NV + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(hacc[pt][2] + hw[3 * CH + 2], 0.0f));
-        }
-      }
-    }
+    // ---- heads: the three 1x1 convs (+folded BN) + ReLU, straight from the last layer's f32 accumulators (a lane holds
+    // 32 of its cell's 64 channels; the other half sits in lane ^ 32): 3 x 32 FMAs per cell on the VALU against the f32
+    // filter table in LDS (broadcast reads), one cross-half exchange, then the bf16 rows of the heads' Linear inputs
+    heads_from_acc<NPT, Q::NV>(hw, lane, pp, ok, slots, acc, feat, FS);
     STAMP(28);
-    __syncthreads();  // heads done reading before the next group's input overwrites act
-    STAMP(29);
+    STAMP(29);  // (no barrier: the last conv ended with one, and nothing has read act or the weight buffers since)
 #if AZ_TOWER_STAMP
     if (stamp_on) tsv[31] = __builtin_amdgcn_s_memrealtime();
 #endif
