@@ -647,7 +647,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
 // feature rows and the fragment-packed weights are read once per wave, the kernel is one round of 4-wave workgroups).
 // One workgroup = 32 boards.  D[board][n] = sum_k feat[board][k] * W[n][k]: A = features (lane: board l&31, k-half l>>5),
 // B = weights (lane: output n = l&31), so a register of the result is 32 consecutive outputs of one board (coalesced).
-//   policy: wave w computes output tiles w, w+4, ... over K = KP;
+//   policy: wave w of workgroup (x, y) computes output tile 4y + w over K = KP;
 //   value:  wave w computes hidden tile w&1 over K-half w>>1 of KV; halves are summed through LDS, then
 //           v = tanh(sum_n relu(hid[n] + b1[n]) * w2[n] + b2) by a lane butterfly.
 // feat (G, FS) bf16: [0, KP) policy features (NV real), [KP, KP + KV) value features (2 NV real); pads are zero.
@@ -668,8 +668,14 @@ __global__ __launch_bounds__(256, 2) void k_heads(const uint16_t *__restrict__ f
   const uint16_t *fa[MT];  // rows past the batch are computed on a copy of the last row and not stored
 #pragma unroll
   for (int m = 0; m < MT; ++m) fa[m] = feat + (size_t)min(g0 + m * 32 + r, G - 1) * FS + 8 * h;
+  // blockIdx.y = the job: policy output tiles 4y .. 4y+3 (one per wave), or (the last y) the value head -- three times
+  // the workgroups of a one-job-after-the-other kernel, each a third as long: the kernel is bound by L2 latency
+  constexpr int PB = (NTP + 3) / 4;
+  const int job = blockIdx.y;
   // ---- policy
-  for (int nt = wave; nt < NTP; nt += 4) {
+  if (job < PB) {
+    const int nt = job * 4 + wave;
+    if (nt >= NTP) return;
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -696,6 +702,7 @@ __global__ __launch_bounds__(256, 2) void k_heads(const uint16_t *__restrict__ f
           if (g0 + row < G) logits[(size_t)(g0 + row) * NV + n] = acc[m][i] + bias;
         }
     }
+    return;
   }
   // ---- value: hidden tile (wave & 1), K half (wave >> 1)
   {
@@ -771,7 +778,8 @@ int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16
   if (!feat_bf16_dev || !wp_dev || !bp_dev || !w1_dev || !b1_dev || !w2_dev || !logits_dev || !values_dev) { g_tower_err = "null argument"; return AZ_EINVAL; }
   if (n_boards < 1 || (board_size != 9 && board_size != 15)) { g_tower_err = "n_boards >= 1, board_size 9 or 15"; return AZ_EINVAL; }
   if (feat_stride < az_heads_feat_stride(board_size) || (feat_stride & 7)) { g_tower_err = "feat_stride: a multiple of 8, at least az_heads_feat_stride(board_size)"; return AZ_EINVAL; }
-  const dim3 grid((n_boards + 31) / 32), block(256);  // k_heads: MT * 32 boards per workgroup
+  const int ntp = (board_size * board_size + 31) / 32;
+  const dim3 grid((n_boards + 31) / 32, (ntp + 3) / 4 + 1), block(256);  // k_heads: 32 boards x one job (4 policy tiles | value) per workgroup
   hipStream_t s = (hipStream_t)stream;
   if (board_size == 15)
     hipLaunchKernelGGL((k_heads<225>), grid, block, 0, s, (const uint16_t *)feat_bf16_dev, (int)feat_stride, (int)n_boards, (const char *)wp_dev,
