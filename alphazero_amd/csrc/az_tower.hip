@@ -40,9 +40,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-constexpr int CH = 64;          // trunk width
-constexpr int TAP_BYTES = 8192; // one tap of a 64->64 layer: [ks 4][half 2][co 64][8] bf16
-constexpr int HW_BYTES = 784;   // head weights in LDS (3*64+3 floats)
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
   const __bf16 x = (__bf16)a, y = (__bf16)b;
@@ -56,24 +53,38 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 // fragment reads of the inner loop).
 __device__ __forceinline__ int fresh(int v) { asm volatile("" : "+v"(v)); return v; }
 
-__device__ __forceinline__ int act_addr(int p, int chunk) { return p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4); }
+// byte offset of 16-byte channel chunk `chunk` of cell p: rows of 2C bytes, chunks XOR-swizzled so that the 16 lanes of a
+// ds_read_b128 group (16 consecutive cells, same logical chunk) cover all 64 banks
+template <int C>
+__device__ __forceinline__ int act_addr(int p, int chunk) {
+  if (C == 64) return p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4);
+  return p * 256 + ((chunk ^ (p & 15)) << 4);
+}
 
-// N = board, BPW = boards per workgroup, NPT = 32-cell tiles per wave (4 waves), ST = taps staged per barrier
-template <int N, int BPW, int NPT, int ST_, int NW_ = 4>
+// N = board, BPW = boards per workgroup, NPT = 32-cell tiles per wave, ST = taps staged per barrier, C = trunk width
+// (64 or 128).  Four waves share the cells; with C = 128 a second set of four waves (w + 4) computes the upper 64
+// output channels of the same cells (8 waves, one workgroup per CU).
+template <int N, int BPW, int NPT, int ST_, int C_>
 struct Geo {
-  static constexpr int NW = NW_;  // waves per workgroup
+  static constexpr int C = C_, CS = C / 64, NW = 4 * CS;  // waves per workgroup
+  static constexpr int KS = C / 16;                        // 16-channel k-steps per tap
+  static constexpr int KB = C * 16;                        // bytes of one (k-step, k-half) weight block: C rows of 8 bf16
+  static constexpr int TAP_BYTES = KS * 2 * KB;            // one tap of a C->C layer: [ks][half 2][co C][8] bf16
+  static constexpr int ROW = 2 * C;                        // bytes per cell
   static constexpr int NV = N * N, NVT = BPW * NV, ST = ST_;
-  static constexpr int ZERO_OFF = NVT * 128;       // one all-zero 128-byte row: where taps off the board read
-  static constexpr int ACT_BYTES = NVT * 128 + 128;
+  static constexpr int ZERO_OFF = NVT * ROW;               // one all-zero row: where taps off the board read
+  static constexpr int ACT_BYTES = NVT * ROW + ROW;
   static constexpr int STAGE_BYTES = ST * TAP_BYTES;
+  static constexpr int HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16;  // head filters + biases in LDS, f32
+  static constexpr int HP_BYTES = CS > 1 ? 4 * NPT * 32 * 3 * 4 : 0; // partial head sums of the upper-channel waves
   static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = BPW * 8 * SWB;  // packed input words per group
   static constexpr int RG_BYTES = ((RGW * 4 + 8 * BPW + 4 + 15) / 16) * 16;     // ring words, BPW players, BPW slots, the group's ticket
-  static_assert(NVT <= NW * NPT * 32, "NW waves x NPT tiles of 32 cells");
+  static_assert(C == 64 || C == 128, "trunk width 64 or 128");
+  static_assert(NVT <= 4 * NPT * 32, "4 cell-waves x NPT tiles of 32 cells");
   static_assert(NPT == 2 || NPT == 4, "conv_layer counts its fragment reads for 2 or 4 cell tiles per wave");
   static_assert(RGW * 4 <= 64 * 16, "one 16-byte LDS-DMA per lane moves the packed input");
-  static size_t lds_bytes(int n_layers) {
-    (void)n_layers;  // any depth: the bias table is a three-layer ring
-    return (size_t)ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + 3 * CH * 4;
+  static size_t lds_bytes() {  // any depth: the bias table is a three-layer ring
+    return (size_t)ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + 2 * RG_BYTES + 3 * C * 4 + HP_BYTES;
   }
 };
 
@@ -104,9 +115,6 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 #define AZ_TOWER15_NPT 2
 #define AZ_TOWER15_ST 3
 #endif
-#ifndef AZ_TOWER15_NW
-#define AZ_TOWER15_NW 4  // waves per workgroup (8 with BPW 2: two boards share one weight stream, one workgroup per CU)
-#endif
 #ifndef AZ_TOWER9_ST
 #define AZ_TOWER9_ST 1  // 9x9 (3 boards per workgroup): per-tap staging keeps two workgroups within a CU's 160 KiB of LDS
 #endif
@@ -121,12 +129,12 @@ __device__ __forceinline__ void glds16o(const char *g_lane, char *lds_base) {
                                    (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)lds_base, 16, OFF, 0);
 }
 
-// stage ST taps of weights (NCHUNK = ST*KS*2 KiB, [tap][ks][half][co][8] bf16, contiguous in global memory and in the
+// stage ST taps of weights (NCHUNK = ST*KS*2*(C/64) KiB, [tap][ks][half][co][8] bf16, contiguous in global memory and in the
 // LDS buffer alike): 1 KiB per wave-instruction, each wave a run of consecutive pieces, four pieces per address
 // pair through the instruction's immediate offset -- a handful of instructions per stage, issued under the MFMAs
-template <int KS, int ST, int NW>
+template <int KS, int ST, int NW, int CS>
 __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave, int lane) {
-  constexpr int NCHUNK = ST * KS * 2, PW = (NCHUNK + NW - 1) / NW;
+  constexpr int NCHUNK = ST * KS * 2 * CS, PW = (NCHUNK + NW - 1) / NW;
 #if AZ_TOWER_ABLATE == 3  // diagnostic build: no weight streaming at all
   return;
 #endif
@@ -160,15 +168,16 @@ __device__ __forceinline__ void stage_w(const char *wg_src, char *dst, int wave,
 // fragment just before its MFMA and waits lgkmcnt(0) every time (one exposed LDS round trip per two MFMAs).
 // BS = bytes between the two weight buffers; STN = taps per stage of the NEXT layer (the stem, 18 KiB of weights in all,
 // runs as one stage without any intermediate barrier when a buffer holds it).
-template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST, int NW, int STN, int BS>
+template <int KS, int KSN, int N, int ZERO_OFF, int NPT, int ST, int NW, int STN, int BS, int C>
 __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext,
                                            int tid, int lane, const int (&pp)[NPT], const uint32_t (&vm)[NPT],
                                            f32x16 (&acc)[NPT][2], unsigned long long *twait = nullptr) {
-  constexpr int TB = KS * 2048;  // bytes per tap
+  constexpr int KB = C * 16, TB = KS * 2 * KB;  // bytes per (k-step, k-half) block, per tap
   constexpr int NSTAGE = 9 / ST, STAGE_BYTES = BS, NK = ST * KS;
-  static_assert(ST * TB <= BS && STN * KSN * 2048 <= BS, "a stage fits its buffer");
+  static_assert(ST * TB <= BS && STN * KSN * 2 * KB <= BS, "a stage fits its buffer");
   constexpr bool XPF = (NK % 2 == 0) && NSTAGE > 1;  // cross-barrier prefetch needs the last k-step in register set 1
   const int h = lane >> 5, r = lane & 31, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cot0 = C > 64 ? (wave >> 2) * 2 : 0;  // this wave's first 32-channel output tile
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
   uint32_t bb[ST][NPT];
   auto bases = [&](int sg) {
@@ -179,7 +188,7 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
 #pragma unroll
       for (int pt = 0; pt < NPT; ++pt) {
         const uint32_t q = (uint32_t)(pp[pt] + d);
-        const uint32_t in = (q << 7) | ((((q >> 1) & 7u) ^ (uint32_t)h) << 4);
+        const uint32_t in = C == 64 ? (q << 7) | ((((q >> 1) & 7u) ^ (uint32_t)h) << 4) : (q << 8) | (((q & 15u) ^ (uint32_t)h) << 4);
         bb[j][pt] = ((vm[pt] >> tap) & 1u) ? in : (uint32_t)(ZERO_OFF | (h << 4));
       }
     }
@@ -199,15 +208,15 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
   if (XPF) load_b(0, 0);
 #pragma unroll 1
   for (int sg = 0; sg < NSTAGE; ++sg) {
-    const uint32_t wa32 = (uint32_t)(uintptr_t)(wbuf + ((buf + sg) & 1) * STAGE_BYTES + h * 1024 + r * 16);
+    const uint32_t wa32 = (uint32_t)(uintptr_t)(wbuf + ((buf + sg) & 1) * STAGE_BYTES + h * KB + (cot0 * 32 + r) * 16);
     auto load_a = [&](int i, int s) {
       const int j = i / KS, ks = i % KS;
 #if AZ_TOWER_ABLATE == 2 || AZ_TOWER_ABLATE == 4
       if (i < 2) fa[s][0] = fa[s][1] = (bf16x8)(__bf16)(AZ_TOWER_ABLATE == 2 ? 1.0f : 0.0f);
       return;
 #endif
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][0]) : "v"(wa32), "i"(j * TB + ks * 2048));
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][1]) : "v"(wa32), "i"(j * TB + ks * 2048 + 512));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][0]) : "v"(wa32), "i"(j * TB + ks * 2 * KB));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][1]) : "v"(wa32), "i"(j * TB + ks * 2 * KB + 512));
     };
     if (!XPF) { if (sg > 0) bases(sg); load_b(0, 0); }
     load_a(0, 0);
@@ -239,8 +248,8 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
       __builtin_amdgcn_sched_barrier(0);
       if (i == 0) {  // the DMA of the next stage's weights: issued under this stage's MFMAs
         char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
-        if (sg < NSTAGE - 1) stage_w<KS, ST, NW>(wg + (sg + 1) * ST * TB, wn, wave, lane);
-        else if (wnext != nullptr) stage_w<KSN, STN, NW>(wnext, wn, wave, lane);
+        if (sg < NSTAGE - 1) stage_w<KS, ST, NW, C / 64>(wg + (sg + 1) * ST * TB, wn, wave, lane);
+        else if (wnext != nullptr) stage_w<KSN, STN, NW, C / 64>(wnext, wn, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -300,8 +309,8 @@ __device__ __forceinline__ void init_acc(const float *bias, int lane, f32x16 (&a
 
 // ReLU, bf16, written back in place.  (Keeping the packed values in registers as the next block's residual instead of
 // reading them back was tried: 32 more live VGPRs across the epilogue, spills, slower.)
-template <int NPT>
-__device__ __forceinline__ void epilogue(char *act, int lane, const int (&pp)[NPT], const bool (&ok)[NPT],
+template <int NPT, int C>
+__device__ __forceinline__ void epilogue(char *act, int lane, int cot0, const int (&pp)[NPT], const bool (&ok)[NPT],
                                          const f32x16 (&acc)[NPT][2]) {
   const int h = fresh(lane) >> 5;
 #pragma unroll
@@ -312,17 +321,21 @@ __device__ __forceinline__ void epilogue(char *act, int lane, const int (&pp)[NP
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint2 v = make_uint2(pack_relu(acc[pt][ct][4 * q + 0], acc[pt][ct][4 * q + 1]), pack_relu(acc[pt][ct][4 * q + 2], acc[pt][ct][4 * q + 3]));
-        if (ok[pt]) *(uint2 *)(act + act_addr(pe, ct * 4 + q) + 8 * h) = v;
+        if (ok[pt]) *(uint2 *)(act + act_addr<C>(pe, (cot0 + ct) * 4 + q) + 8 * h) = v;
       }
   }
 }
 
 // heads' 1x1 convs from the accumulators of the last trunk layer (bias and residual already in them, ReLU applied here in f32).
-// hw: [3][64] filters + [3] biases, f32, in LDS.  acc[pt][ct][4q + j] = channel ct*32 + q*8 + (lane>>5)*4 + j of cell pp[pt].
-template <int NPT, int NV>
-__device__ __forceinline__ void heads_from_acc(const float *hw, int lane_, const int (&pp)[NPT], const bool (&ok)[NPT],
-                                               const int *slots, const f32x16 (&acc)[NPT][2], uint16_t *feat, int FS) {
-  const int lane = fresh(lane_), h = lane >> 5;
+// hw: [3][C] filters + [3] biases, f32, in LDS.  acc[pt][ct][4q + j] = channel (cot0+ct)*32 + q*8 + (lane>>5)*4 + j of cell
+// pp[pt].  C = 128: waves 4..7 hold the upper 64 channels of the cells of waves 0..3 and hand their partial sums over
+// through `hp` (one barrier); waves 0..3 write the rows.
+template <int NPT, int NV, int C>
+__device__ __forceinline__ void heads_from_acc(const float *hw, float *hp, int lane_, int wave, const int (&pp)[NPT],
+                                               const bool (&ok)[NPT], const int *slots, const f32x16 (&acc)[NPT][2],
+                                               uint16_t *feat, int FS) {
+  const int lane = fresh(lane_), h = lane >> 5, r = lane & 31;
+  const int cot0 = C > 64 ? (wave >> 2) * 2 : 0, cw = wave & 3;
   f32x2 hs[NPT][3];
 #pragma unroll
   for (int pt = 0; pt < NPT; ++pt) hs[pt][0] = hs[pt][1] = hs[pt][2] = (f32x2){0.0f, 0.0f};
@@ -335,8 +348,8 @@ __device__ __forceinline__ void heads_from_acc(const float *hw, int lane_, const
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) wv[ct][q][k] = *(const float4 *)(hw + k * CH + ct * 32 + q * 8 + h * 4);
-  const float hb0 = hw[3 * CH + 0], hb1 = hw[3 * CH + 1], hb2 = hw[3 * CH + 2];
+      for (int k = 0; k < 3; ++k) wv[ct][q][k] = *(const float4 *)(hw + k * C + (cot0 + ct) * 32 + q * 8 + h * 4);
+  const float hb0 = hw[3 * C + 0], hb1 = hw[3 * C + 1], hb2 = hw[3 * C + 2];
   int gs[NPT];
 #pragma unroll
   for (int pt = 0; pt < NPT; ++pt) gs[pt] = slots[pp[pt] / NV];
@@ -357,24 +370,40 @@ __device__ __forceinline__ void heads_from_acc(const float *hw, int lane_, const
           hs[pt][k] = __builtin_elementwise_fma(vb, (f32x2){wv[ct][q][k].z, wv[ct][q][k].w}, hs[pt][k]);
         }
       }
-  constexpr int KP = (NV + 15) / 16 * 16;
+  float t[NPT][3];
 #pragma unroll
-  for (int pt = 0; pt < NPT; ++pt) {
-    float t[3];
+  for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {  // own half + the other half-wave's: v_permlane32_swap (no LDS round trip)
       const float own = hs[pt][k][0] + hs[pt][k][1];
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
-      t[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      t[pt][k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
+  if (C > 64) {
+    if (wave >= 4 && h == 0) {
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) hp[((cw * NPT + pt) * 32 + r) * 3 + k] = t[pt][k];
+    }
+    __syncthreads();
+    if (wave >= 4) return;
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t[pt][k] += hp[((cw * NPT + pt) * 32 + r) * 3 + k];
+  }
+  constexpr int KP = (NV + 15) / 16 * 16;
+#pragma unroll
+  for (int pt = 0; pt < NPT; ++pt) {
     if ((pt & 1) != h || !ok[pt]) continue;  // even tiles are written by the lower half-wave, odd ones by the upper
     const int cell = fresh(pp[pt]) % NV, g = gs[pt];
     if (g < 0) continue;
     // the heads' Linear inputs, bf16: [policy NV | pad to 16 | value0 NV | value1 NV | pad] (az_heads_forward reads it)
     uint16_t *fr = feat + (size_t)g * FS;
-    fr[cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(t[0] + hb0, 0.0f));
-    fr[KP + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(t[1] + hb1, 0.0f));
-    fr[KP + NV + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(t[2] + hb2, 0.0f));
+    fr[cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(t[pt][0] + hb0, 0.0f));
+    fr[KP + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(t[pt][1] + hb1, 0.0f));
+    fr[KP + NV + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(t[pt][2] + hb2, 0.0f));
   }
 }
 
@@ -385,44 +414,47 @@ __device__ __forceinline__ void glds4(const void *g_lane, void *lds_base) {
 }
 
 // x: (G, 9, N, N) bf16, or nullptr to read the engine's packed leaf batch (ring u32 (G,8,SWB) + leaf records).
-// w0: [9][1][2][64][8] bf16 (first conv, 9 input channels padded to 16).  wl: [L][9][4][2][64][8] bf16.
-// bias: [1+L][64] f32.  headw: [3][64] f32 (policy, value0, value1), headb: [3].
+// w0: [9][1][2][C][8] bf16 (first conv, 9 input channels padded to 16).  wl: [L][9][C/16][2][C][8] bf16.
+// bias: [1+L][C] f32.  headw: [3][C] f32 (policy, value0, value1), headb: [3].
 // feat: (G, FS) bf16 = the inputs of the heads' Linear layers (layout: see the heads' epilogue and k_heads).
-template <int N, int BPW, int NPT, int ST, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
+template <int N, int BPW, int NPT, int ST, int C>
+__global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
                                                const int4 *__restrict__ leafrec, const int32_t *__restrict__ list,
                                                const int32_t *__restrict__ count, const uint8_t *__restrict__ flags, int G,
                                                const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
                                                uint16_t *__restrict__ feat, int FS, unsigned int *tickets) {
-  using Q = Geo<N, BPW, NPT, ST, NW>;
+  using Q = Geo<N, BPW, NPT, ST, C>;
+  constexpr int NW = Q::NW, KS = Q::KS, TAP_BYTES = Q::TAP_BYTES;
   constexpr int WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RG_STRIDE = Q::RG_BYTES, STAGE_BYTES = Q::STAGE_BYTES, NTH = NW * 64;
-  // the stem's taps per stage: all nine (18 KiB, no barrier inside the layer) when a weight buffer holds them
+  // the stem's taps per stage: all nine (18 KiB at C = 64, no barrier inside the layer) when a weight buffer holds them
 #ifdef AZ_TOWER_STEM_ST
   constexpr int ST0 = AZ_TOWER_STEM_ST;
 #else
-  constexpr int ST0 = 9 * 2048 <= STAGE_BYTES ? 9 : (3 * 2048 <= STAGE_BYTES ? 3 : 1);
+  constexpr int ST0 = 9 * 2 * Q::KB <= STAGE_BYTES ? 9 : (3 * 2 * Q::KB <= STAGE_BYTES ? 3 : 1);
 #endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *act = smem;
   char *wbuf = smem + Q::ACT_BYTES;
-  float *hw = (float *)(wbuf + 2 * STAGE_BYTES);  // 3*64 + 3 floats
-  char *rgb = wbuf + 2 * STAGE_BYTES + HW_BYTES;  // 2 x {RGW ring words, BPW player words}
-  float *bl = (float *)(rgb + 2 * RG_STRIDE);     // 3 x 64 biases: the running layer's, the next one's (DMA'd under this layer's conv), the last one's
+  float *hw = (float *)(wbuf + 2 * STAGE_BYTES);  // 3*C + 3 floats
+  char *rgb = wbuf + 2 * STAGE_BYTES + Q::HW_BYTES;  // 2 x {RGW ring words, BPW player words}
+  float *bl = (float *)(rgb + 2 * RG_STRIDE);     // 3 x C biases: the running layer's, the next one's (DMA'd under this layer's conv), the last one's
+  float *hp = bl + 3 * C;                         // (C = 128) partial head sums of waves 4..7
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = wave & 3, cot0 = C > 64 ? (wave >> 2) * 2 : 0;  // cell-wave index; first 32-channel output tile
 
   for (int i = tid; i < Q::ACT_BYTES / 16; i += NTH) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero slot
-  for (int i = tid; i < 3 * CH + 3; i += NTH) hw[i] = i < 3 * CH ? headw[i] : headb[i - 3 * CH];
-  for (int i = tid; i < CH; i += NTH) bl[i] = bias[i];  // the stem's; every later layer's row arrives by LDS-DMA, one layer ahead
+  for (int i = tid; i < 3 * C + 3; i += NTH) hw[i] = i < 3 * C ? headw[i] : headb[i - 3 * C];
+  for (int i = tid; i < C; i += NTH) bl[i] = bias[i];  // the stem's; every later layer's row arrives by LDS-DMA, one layer ahead
 
-  // this lane's NPT cells (B-operand column / accumulator column): tile = NPT*wave + pt
+  // this lane's NPT cells (B-operand column / accumulator column): tile = NPT*cw + pt
   int pp[NPT];
   bool ok[NPT];
   uint32_t vm[NPT];
 #pragma unroll
   for (int pt = 0; pt < NPT; ++pt) {
-    const int m = (NPT * wave + pt) * 32 + (lane & 31);
+    const int m = (NPT * cw + pt) * 32 + (lane & 31);
     ok[pt] = m < Q::NVT;
     pp[pt] = ok[pt] ? m : 0;
     const int cell = pp[pt] % Q::NV, row = cell / N, col = cell % N;
@@ -483,11 +515,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
   int buf = 0, inb = 0, it = 0, bslot = 0;
   // bias row of `layer` -> the ring slot after the running one (wave 0; lands before the running conv's first stage barrier)
   auto bias_ahead = [&](int layer) {
-    if (wave == 0) glds4(bias + layer * CH + lane, (char *)(bl + (bslot == 2 ? 0 : bslot + 1) * CH));
+    if (wave < C / 64) glds4(bias + layer * C + wave * 64 + lane, (char *)(bl + (bslot == 2 ? 0 : bslot + 1) * C + wave * 64));
   };
   auto bias_step = [&]() { bslot = bslot == 2 ? 0 : bslot + 1; };
   // prologue: the stem's first weight stage and the first group's input
-  stage_w<1, ST0, NW>(w0, wbuf, wave, lane);
+  stage_w<1, ST0, NW, C / 64>(w0, wbuf, wave, lane);
   draw();
   lookup();
   fetch(0);
@@ -535,8 +567,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
           c[4] = (int)rg[RGW + b] > 0 ? 0x3F80u : 0xBF80u;
         }
       }
-      *(uint4 *)(act + act_addr(m, 0)) = make_uint4(c[0], c[1], c[2], c[3]);
-      *(uint4 *)(act + act_addr(m, 1)) = make_uint4(c[4], c[5], c[6], c[7]);
+      *(uint4 *)(act + act_addr<C>(m, 0)) = make_uint4(c[0], c[1], c[2], c[3]);
+      *(uint4 *)(act + act_addr<C>(m, 1)) = make_uint4(c[4], c[5], c[6], c[7]);
     }
     inb ^= 1;
     __syncthreads();
@@ -545,15 +577,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
     f32x16 acc[NPT][2];
     uint2 res[NPT][2][4];
     // ---- stem
-    init_acc<false, NPT>(bl + bslot * CH, lane, acc, res);
+    init_acc<false, NPT>(bl + bslot * C + cot0 * 32, lane, acc, res);
     if (L > 0) bias_ahead(1);
     else bias_ahead(0);  // (the next group's stem; harmless when there is none)
-    if (L > 0) conv_layer<1, 4, N, Q::ZERO_OFF, NPT, ST0, NW, ST, STAGE_BYTES>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
-    else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST0, NW, ST0, STAGE_BYTES>(act, wbuf, buf, w0, w0, tid, lane, pp, vm, acc);
+    if (L > 0) conv_layer<1, KS, N, Q::ZERO_OFF, NPT, ST0, NW, ST, STAGE_BYTES, C>(act, wbuf, buf, w0, wl, tid, lane, pp, vm, acc);
+    else conv_layer<1, 1, N, Q::ZERO_OFF, NPT, ST0, NW, ST0, STAGE_BYTES, C>(act, wbuf, buf, w0, w0, tid, lane, pp, vm, acc);
     STAMP(2);
     bias_step();
     if (L > 0) {
-      epilogue<NPT>(act, lane, pp, ok, acc);
+      epilogue<NPT, C>(act, lane, cot0, pp, ok, acc);
       __syncthreads();
     }
     STAMP(3);
@@ -569,7 +601,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr(pe, ct * 4 + q) + 8 * h);
+            for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr<C>(pe, (cot0 + ct) * 4 + q) + 8 * h);
         }
       }
 #if AZ_TOWER_STAMP
@@ -578,31 +610,31 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
 #else
       unsigned long long *twp = nullptr;
 #endif
-      init_acc<false, NPT>(bl + bslot * CH, lane, acc, res);
+      init_acc<false, NPT>(bl + bslot * C + cot0 * 32, lane, acc, res);
       bias_ahead(2 + l);
       STAMP(sk + 0);
-      conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST, NW, ST, STAGE_BYTES>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
+      conv_layer<KS, KS, N, Q::ZERO_OFF, NPT, ST, NW, ST, STAGE_BYTES, C>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES, tid,
                                        lane, pp, vm, acc, twp);
       STAMP(sk + 1);
       bias_step();
-      epilogue<NPT>(act, lane, pp, ok, acc);
+      epilogue<NPT, C>(act, lane, cot0, pp, ok, acc);
       __syncthreads();
       STAMP(sk + 2);
       if (l == 0) fetch(inb);  // the next group's packed input: lands under the rest of this group's tower
-      init_acc<true, NPT>(bl + bslot * CH, lane, acc, res);
+      init_acc<true, NPT>(bl + bslot * C + cot0 * 32, lane, acc, res);
       if (l + 2 < L) bias_ahead(3 + l);
       else bias_ahead(0);
       STAMP(sk + 3);
       if (l + 2 < L)
-        conv_layer<4, 4, N, Q::ZERO_OFF, NPT, ST, NW, ST, STAGE_BYTES>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
+        conv_layer<KS, KS, N, Q::ZERO_OFF, NPT, ST, NW, ST, STAGE_BYTES, C>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, wl + (size_t)(l + 2) * 9 * TAP_BYTES,
                                          tid, lane, pp, vm, acc, twp);
       else  // last layer of this board: prefetch the next board's stem weights
-        conv_layer<4, 1, N, Q::ZERO_OFF, NPT, ST, NW, ST0, STAGE_BYTES>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, w0, tid, lane,
+        conv_layer<KS, 1, N, Q::ZERO_OFF, NPT, ST, NW, ST0, STAGE_BYTES, C>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * TAP_BYTES, w0, tid, lane,
                                          pp, vm, acc, twp);
       STAMP(sk + 4);
       bias_step();
       if (l + 2 < L) {  // (the last layer's output stays in the accumulators for the heads)
-        epilogue<NPT>(act, lane, pp, ok, acc);
+        epilogue<NPT, C>(act, lane, cot0, pp, ok, acc);
         __syncthreads();
       }
       STAMP(sk + 5);
@@ -613,7 +645,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1)) v
     // ---- heads: the three 1x1 convs (+folded BN) + ReLU, straight from the last layer's f32 accumulators (a lane holds
     // 32 of its cell's 64 channels; the other half sits in lane ^ 32): 3 x 32 FMAs per cell on the VALU against the f32
     // filter table in LDS (broadcast reads), one cross-half exchange, then the bf16 rows of the heads' Linear inputs
-    heads_from_acc<NPT, Q::NV>(hw, lane, pp, ok, slots, acc, feat, FS);
+    heads_from_acc<NPT, Q::NV, C>(hw, hp, lane, wave, pp, ok, slots, acc, feat, FS);
     STAMP(28);
     STAMP(29);  // (no barrier: the last conv ended with one, and nothing has read act or the weight buffers since)
 #if AZ_TOWER_STAMP
@@ -792,7 +824,7 @@ int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16
   return AZ_OK;
 }
 
-int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
+int az_tower_forward(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
                      const void *packed_ring_dev, const void *packed_leaf_dev, const void *list_dev,
                      const void *count_dev, const void *flags_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev,
                      const float *headw_dev, const float *headb_dev, void *feat_bf16_dev, int32_t feat_stride, void *stream) {
@@ -800,6 +832,7 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
   if ((!x_bf16_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !feat_bf16_dev ||
       (n_conv_layers > 0 && !wl_dev)) { g_tower_err = "null argument"; return AZ_EINVAL; }
   if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1)) { g_tower_err = "n_boards >= 1, even n_conv_layers"; return AZ_EINVAL; }
+  if ((board_size != 9 && board_size != 15) || (channels != 64 && channels != 128)) { g_tower_err = "board_size must be 9 or 15, channels 64 or 128"; return AZ_EINVAL; }
   if (feat_stride < az_heads_feat_stride(board_size)) { g_tower_err = "feat_stride below az_heads_feat_stride(board_size)"; return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   hipError_t err;
@@ -818,10 +851,10 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
     }
     tickets = g_ticket_base[dev] + 2 * (g_ticket_seq[dev]++ % AZ_TOWER_TICKET_PAIRS);
   }
-  auto launch = [&](auto kern, size_t lds, int bpw, int nw) -> int {
-    if (lds > 160 * 1024) { g_tower_err = "tower geometry exceeds the CU's LDS"; return AZ_EINVAL; }
+  auto launch = [&](auto kern, size_t lds, int bpw, int nw, int wg_per_cu) -> int {
+    if (lds * wg_per_cu > 160 * 1024) { g_tower_err = "tower geometry exceeds the CU's LDS"; return AZ_EINVAL; }
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * (nw == 4 ? AZ_TOWER_WAVES_PER_SIMD : 1);  // workgroups that fit the chip
+    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * wg_per_cu;  // workgroups that fit the chip
     const int grid = groups < cap ? groups : cap;
     const bool use_list = !x_bf16_dev && list_dev && count_dev;
     const bool use_flags = !x_bf16_dev && !use_list && flags_dev;
@@ -831,15 +864,19 @@ int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers
                        n_conv_layers, headw_dev, headb_dev, (uint16_t *)feat_bf16_dev, (int)feat_stride, tickets);
     return AZ_OK;
   };
+  // 64 channels: 4 waves, two workgroups per CU.  128 channels: 8 waves (two sets of four, 64 output channels each), one
+  // workgroup per CU, one tap (32 KiB of weights) per stage.
   int rc;
-  if (board_size == 15) {
-    rc = launch(k_tower<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, AZ_TOWER15_NW>,
-                Geo<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, AZ_TOWER15_NW>::lds_bytes(n_conv_layers), AZ_TOWER15_BPW, AZ_TOWER15_NW);
-  } else if (board_size == 9) {
-    rc = launch(k_tower<9, 3, 2, AZ_TOWER9_ST, 4>, Geo<9, 3, 2, AZ_TOWER9_ST, 4>::lds_bytes(n_conv_layers), 3, 4);
+  if (channels == 64) {
+    using G15 = Geo<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, 64>;
+    using G9 = Geo<9, 3, 2, AZ_TOWER9_ST, 64>;
+    if (board_size == 15) rc = launch(k_tower<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, 64>, G15::lds_bytes(), AZ_TOWER15_BPW, G15::NW, AZ_TOWER_WAVES_PER_SIMD);
+    else rc = launch(k_tower<9, 3, 2, AZ_TOWER9_ST, 64>, G9::lds_bytes(), 3, G9::NW, AZ_TOWER_WAVES_PER_SIMD);
   } else {
-    g_tower_err = "board_size must be 9 or 15";
-    return AZ_EINVAL;
+    using G15 = Geo<15, 1, 2, 1, 128>;
+    using G9 = Geo<9, 3, 2, 1, 128>;
+    if (board_size == 15) rc = launch(k_tower<15, 1, 2, 1, 128>, G15::lds_bytes(), 1, G15::NW, 1);
+    else rc = launch(k_tower<9, 3, 2, 1, 128>, G9::lds_bytes(), 3, G9::NW, 1);
   }
   if (rc != AZ_OK) return rc;
   err = hipGetLastError();

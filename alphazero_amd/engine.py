@@ -78,7 +78,7 @@ def load_library() -> C.CDLL:
     lib.az_reset_stats.argtypes = [vp, vp]
     lib.az_eval_hash.argtypes = [vp, vp, C.c_float, vp, vp, vp]
     lib.az_augment_samples.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
-    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]
+    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]
     lib.az_heads_forward.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
     lib.az_heads_feat_stride.argtypes = [C.c_int32]
     lib.az_heads_feat_stride.restype = C.c_int32

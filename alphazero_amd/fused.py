@@ -1,5 +1,6 @@
 """Fused evaluator for GomokuModel-family networks (examples/gomoku/model.py:41-90 and
-alphazero_amd.nets.GomokuNet): the conv tower runs as ONE hand-written bf16 MFMA kernel
+alphazero_amd.nets.GomokuNet; trunk width 64 or 128, any number of residual blocks, board 9 or 15): the conv tower
+runs as ONE hand-written bf16 MFMA kernel
 (csrc/az_tower.hip, activations resident in LDS); eval-mode BatchNorm is folded into the conv weights
 here; the heads' Linear layers run as one more small MFMA kernel (az_heads_forward).  Same contract as the module it wraps:
 ``(B, 9, N, N) -> (logits (B, N*N) f32, value (B, 1) f32)``.  Call ``refresh()`` after the module's
@@ -24,7 +25,7 @@ def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
 
 
 def _pack3x3(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
-    """(co=64, ci, 3, 3) f32 -> [tap 9][k-step][k-half 2][co 64][8] bf16"""
+    """(co, ci, 3, 3) f32 -> [tap 9][k-step][k-half 2][co][8] bf16"""
     co, ci = w.shape[0], w.shape[1]
     if ci < cin_pad:
         w = torch.cat([w, w.new_zeros(co, cin_pad - ci, 3, 3)], 1)
@@ -47,9 +48,11 @@ class FusedTowerEvaluator:
         try:
             sl = model._shared_layers
             stem, blocks = sl[0], [m for m in list(sl)[3:]]
-            ok = isinstance(stem, nn.Conv2d) and stem.in_channels == 9 and stem.out_channels == 64 and \
+            ch = stem.out_channels
+            ok = isinstance(stem, nn.Conv2d) and stem.in_channels == 9 and ch in (64, 128) and \
                 stem.kernel_size == (3, 3) and isinstance(sl[1], nn.BatchNorm2d)
-            ok = ok and all(hasattr(b, "_conv1") and hasattr(b, "_bn2") and b._conv1.out_channels == 64 for b in blocks)
+            ok = ok and all(hasattr(b, "_conv1") and hasattr(b, "_bn2") and b._conv1.out_channels == ch and
+                            b._conv1.in_channels == ch and b._conv2.out_channels == ch for b in blocks)
             ph, vh = model._policy_head, model._value_head
             ok = ok and ph[0].out_channels == 1 and vh[0].out_channels == 2 and isinstance(ph[4], nn.Linear) \
                 and isinstance(vh[4], nn.Linear) and isinstance(vh[6], nn.Linear)
@@ -60,7 +63,7 @@ class FusedTowerEvaluator:
 
     def __init__(self, model: nn.Module):
         if not self.supports(model):
-            raise EngineError("FusedTowerEvaluator: not a GomokuModel-family network (64-ch 3x3 residual tower)")
+            raise EngineError("FusedTowerEvaluator: not a GomokuModel-family network (64- or 128-channel 3x3 residual tower)")
         self.lib = load_library()
         self.model = model
         self.device = next(model.parameters()).device
@@ -68,6 +71,7 @@ class FusedTowerEvaluator:
             raise EngineError("FusedTowerEvaluator needs the model on a GPU")
         self.n2 = model._policy_head[4].in_features
         self.board = 15 if self.n2 == 225 else 9
+        self.ch = model._shared_layers[0].out_channels
         self._buf = {}
         self.kernel_events = None  # bench.py sets this to a list: (start, end) HIP events around the tower kernel alone
         self.refresh()
@@ -83,14 +87,14 @@ class FusedTowerEvaluator:
         for blk in blocks:
             for conv, bn in ((blk._conv1, blk._bn1), (blk._conv2, blk._bn2)):
                 w, b = _fold(conv, bn)
-                wl.append(_pack3x3(w, 64))
+                wl.append(_pack3x3(w, self.ch))
                 biases.append(b)
         self.n_layers = len(wl)
         self.wl = (torch.stack(wl) if wl else torch.zeros(1, dtype=torch.bfloat16)).to(dev).contiguous()
         self.bias = torch.stack(biases).to(dev).contiguous()
         pw, pb = _fold(m._policy_head[0], m._policy_head[1])
         vw, vb = _fold(m._value_head[0], m._value_head[1])
-        self.headw = torch.cat([pw.view(1, 64), vw.view(2, 64)]).to(dev).contiguous()
+        self.headw = torch.cat([pw.view(1, self.ch), vw.view(2, self.ch)]).to(dev).contiguous()
         self.headb = torch.cat([pb.view(1), vb.view(2)]).to(dev).contiguous()
         f = lambda t: t.detach().float().to(dev).contiguous()
         pl, v1, v2 = m._policy_head[4], m._value_head[4], m._value_head[6]
@@ -137,7 +141,7 @@ class FusedTowerEvaluator:
         if self.kernel_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        rc = self.lib.az_tower_forward(self.board, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
+        rc = self.lib.az_tower_forward(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
                                        list_p, count_p, flags_p, P(self.w0), P(self.wl), P(self.bias),
                                        P(self.headw), P(self.headb), P(feat), self.feat_stride, st)
         if rc != 0:

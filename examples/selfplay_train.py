@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--slots", type=int, default=16384)
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--blocks", type=int, default=10)
+    ap.add_argument("--channels", type=int, default=128, choices=[64, 128], help="trunk width (both run on the fused MFMA tower)")
     ap.add_argument("--board", type=int, default=15, choices=[9, 15])
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--train-steps-per-move", type=int, default=4)
@@ -37,7 +38,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(1234 + rank)
-    loop = SelfPlayTrainLoop(GomokuNet(args.board, 64, args.blocks), 2, args.board, args.slots, args.sims, dev,
+    loop = SelfPlayTrainLoop(GomokuNet(args.board, args.channels, args.blocks), 2, args.board, args.slots, args.sims, dev,
                              batch_size=args.batch, train_steps_per_move=args.train_steps_per_move)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

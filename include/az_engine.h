@@ -195,14 +195,15 @@ int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *log
  *   of the same board size; both may be NULL when x_bf16_dev is given); with list_dev / count_dev (same call,
  *   or NULL) only the listed slots are evaluated and only their rows of feat are written; with flags_dev (same
  *   call; used when no list is given) only the slots whose flag byte is non-zero -- no compaction launch needed;
- *   w0_dev [9][1][2][64][8] bf16, wl_dev [n_conv_layers][9][4][2][64][8] bf16 ([tap][k-step][k-half][co][8 ci]);
- *   bias_dev [1+n_conv_layers][64] f32; headw_dev [3][64] f32, headb_dev [3] f32 (policy, value0, value1);
+ *   channels C in {64, 128} = the trunk width;
+ *   w0_dev [9][1][2][C][8] bf16, wl_dev [n_conv_layers][9][C/16][2][C][8] bf16 ([tap][k-step][k-half][co][8 ci]);
+ *   bias_dev [1+n_conv_layers][C] f32; headw_dev [3][C] f32, headb_dev [3] f32 (policy, value0, value1);
  *   feat_bf16_dev (n_boards, feat_stride) bf16 out: the inputs of the heads' Linear layers, row layout
  *   [policy N*N | zero pad to a multiple of 16 | value0 N*N | value1 N*N | zero pad to a multiple of 16];
  *   feat_stride >= az_heads_feat_stride(N) elements; the pads are never written: hand in a zeroed buffer.
  *   board_size N in {9, 15}.  Groups of boards are handed to workgroups through a ticket counter that lives in the
  *   library (16 pairs per GPU, rotated per launch): at most 16 launches may be in flight on one GPU. */
-int az_tower_forward(int32_t board_size, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
+int az_tower_forward(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
                      const void *packed_ring_dev, const void *packed_leaf_dev, const void *list_dev,
                      const void *count_dev, const void *flags_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev,
                      const float *headw_dev, const float *headb_dev, void *feat_bf16_dev, int32_t feat_stride, void *stream);

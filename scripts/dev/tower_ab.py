@@ -16,7 +16,7 @@ board = int(os.environ.get("BOARD", "15"))
 B = int(os.environ.get("BATCH", "16384"))
 blocks = int(os.environ.get("BLOCKS", "2"))
 torch.manual_seed(0)
-net = GomokuNet(board, 64, blocks).eval().cuda()
+net = GomokuNet(board, int(os.environ.get("CHANNELS", "64")), blocks).eval().cuda()
 ev = FusedTowerEvaluator(net)
 x = torch.randint(-1, 2, (B, 9, board, board), device="cuda").to(torch.bfloat16)
 if os.environ.get("ZERO"):  # all-zero weights and inputs: same instruction stream, minimal switching power
@@ -29,13 +29,13 @@ P = lambda t: C.c_void_p(t.data_ptr())
 libs = []
 for path in sys.argv[1:]:
     lib = C.CDLL(os.path.join(ROOT, path))
-    lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 12 + [C.c_int32, C.c_void_p]
+    lib.az_tower_forward.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 12 + [C.c_int32, C.c_void_p]
     libs.append((path, lib))
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def run(lib):
-    rc = lib.az_tower_forward(board, B, ev.n_layers, P(x), None, None, None, None, None, P(ev.w0), P(ev.wl), P(ev.bias),
+    rc = lib.az_tower_forward(board, ev.ch, B, ev.n_layers, P(x), None, None, None, None, None, P(ev.w0), P(ev.wl), P(ev.bias),
                               P(ev.headw), P(ev.headb), P(pfeat), ev.feat_stride, st)
     assert rc == 0, rc
 

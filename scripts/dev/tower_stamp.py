@@ -12,10 +12,10 @@ x = torch.randint(-1, 2, (B, 9, 15, 15), device="cuda").to(torch.bfloat16)
 ev(x)
 vfeat = ev._buf[B][0]
 lib = C.CDLL(os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "alphazero_amd/lib/dev/stamp.so"))
-lib.az_tower_forward.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 12 + [C.c_int32, C.c_void_p]
+lib.az_tower_forward.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 12 + [C.c_int32, C.c_void_p]
 P = lambda t: C.c_void_p(t.data_ptr())
 for _ in range(int(os.environ.get("REPS", "200"))):  # long enough for the clock to settle under load
-    lib.az_tower_forward(15, B, ev.n_layers, P(x), None, None, None, None, None, P(ev.w0), P(ev.wl), P(ev.bias), P(ev.headw), P(ev.headb), P(vfeat), ev.feat_stride, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    lib.az_tower_forward(15, ev.ch, B, ev.n_layers, P(x), None, None, None, None, None, P(ev.w0), P(ev.wl), P(ev.bias), P(ev.headw), P(ev.headb), P(vfeat), ev.feat_stride, C.c_void_p(torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
 t = vfeat.view(-1)[:512].view(torch.int64).view(4, 32).cpu()
 names = {0: "start", 1: "input+bar", 2: "stem conv", 3: "stem epi+bar", 28: "heads", 29: "final bar"}

@@ -19,14 +19,15 @@ def _randomised(net):
     return net
 
 
-@pytest.mark.parametrize("board,blocks,batch", [(15, 2, 64), (15, 2, 1000), (15, 3, 33), (9, 2, 100), (9, 1, 7), (15, 0, 5), (15, 10, 600),
-                                                (9, 6, 50)])
-def test_fused_tower_matches_fp32_forward(board, blocks, batch):
+@pytest.mark.parametrize("board,blocks,batch,ch", [(15, 2, 64, 64), (15, 2, 1000, 64), (15, 3, 33, 64), (9, 2, 100, 64), (9, 1, 7, 64),
+                                                   (15, 0, 5, 64), (15, 10, 600, 64), (9, 6, 50, 64),
+                                                   (15, 2, 300, 128), (15, 10, 520, 128), (9, 3, 100, 128), (15, 0, 9, 128)])
+def test_fused_tower_matches_fp32_forward(board, blocks, batch, ch):
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import GomokuNet
 
     torch.manual_seed(0)
-    net = _randomised(GomokuNet(board, 64, blocks)).eval().cuda()
+    net = _randomised(GomokuNet(board, ch, blocks)).eval().cuda()
     assert FusedTowerEvaluator.supports(net)
     ev = FusedTowerEvaluator(net)
     x = torch.randint(-1, 2, (batch, 9, board, board), device="cuda").float()
@@ -41,7 +42,7 @@ def test_fused_tower_matches_fp32_forward(board, blocks, batch):
     assert float((v - ref_v).abs().max()) <= 0.03
     assert float((p - ref_p).abs().mean()) <= 0.004 * scale + 0.002
     # and it must beat / match the plain bf16 PyTorch forward's own error
-    netb = GomokuNet(board, 64, blocks)
+    netb = GomokuNet(board, ch, blocks)
     netb.load_state_dict(net.state_dict())
     netb = netb.eval().cuda().bfloat16()
     with torch.inference_mode():
@@ -54,11 +55,12 @@ def test_fused_tower_rejects_other_nets():
     from alphazero_amd.nets import GomokuNet, TicTacToeNet
 
     assert not FusedTowerEvaluator.supports(TicTacToeNet())
-    assert not FusedTowerEvaluator.supports(GomokuNet(15, 128, 2))
+    assert not FusedTowerEvaluator.supports(GomokuNet(15, 96, 2))
+    assert FusedTowerEvaluator.supports(GomokuNet(15, 128, 2))
 
 
-@pytest.mark.parametrize("board", [15, 9])
-def test_packed_leaf_batch_equals_dense_planes(board):
+@pytest.mark.parametrize("board,ch", [(15, 64), (9, 64), (15, 128)])
+def test_packed_leaf_batch_equals_dense_planes(board, ch):
     """The tower fed from the engine's packed leaf batch (bitboards) == fed from the dense bf16 planes."""
     from alphazero_amd import Engine
     from alphazero_amd.fused import FusedTowerEvaluator
@@ -66,7 +68,7 @@ def test_packed_leaf_batch_equals_dense_planes(board):
 
     torch.manual_seed(0)
     G, sims = 200, 12
-    net = _randomised(GomokuNet(board, 64, 2)).eval().cuda()
+    net = _randomised(GomokuNet(board, ch, 2)).eval().cuda()
     ev = FusedTowerEvaluator(net)
     eng = Engine(2, G, sims, board_size=board, nn_dtype=torch.bfloat16, device="cuda:0")
     nn = eng.new_nn_input()
