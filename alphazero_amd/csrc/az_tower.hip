@@ -512,7 +512,8 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) voi
       glds16((const char *)ring + (size_t)dma_slot * BOARD_BYTES + (lane * 16) % BOARD_BYTES, dst);
     if (lane < BPW && sl_next >= 0) glds4(&leafrec[sl_next].w, dst + RGW * 4);
   };
-  int buf = 0, inb = 0, it = 0, bslot = 0;
+  int buf = 0, inb = 0, bslot = 0;
+  [[maybe_unused]] int it = 0;  // boards done (read by the stamp build only)
   // bias row of `layer` -> the ring slot after the running one (wave 0; lands before the running conv's first stage barrier)
   auto bias_ahead = [&](int layer) {
     if (wave < C / 64) glds4(bias + layer * C + wave * 64 + lane, (char *)(bl + (bslot == 2 ? 0 : bslot + 1) * C + wave * 64));
