@@ -181,17 +181,38 @@ __device__ __forceinline__ void load_ring(const uint32_t *tb, int ply, uint32_t 
 // action wins ties), q64 = +child.value if the child has the parent's player else -child.value.
 // One dependent memory round trip per level: the three child streams are read together, and the winner's
 // meta word and visit count travel through the argmax butterfly, so nothing is re-read.
+// What a descent needs before its first tree level: the slot's words and this lane's share of the history ring + the
+// current board.  k_expand_select fills it while the expansion of the previous simulation runs (the words are the
+// ones the expansion reads or writes anyway, the ring only depends on the ply), so the descent starts without the
+// two memory round trips a stand-alone k_select_gather spends here.
+template <class GT>
+struct SelPre {
+  static constexpr int RW = (8 * GT::SW + 63) / 64;  // ring words per lane
+  bool active;
+  int ply, player, used, rootN;
+  uint32_t rw[RW], cw;
+};
+template <class GT>
+__device__ __forceinline__ void sel_load_ring(const View &v, const int g, const int lane, SelPre<GT> &s) {
+  const uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
+#pragma unroll
+  for (int k = 0; k < SelPre<GT>::RW; ++k) {
+    const int i = lane + 64 * k, hk = i / GT::SW, w = i % GT::SW, t = s.ply - 7 + hk;
+    s.rw[k] = (i < 8 * GT::SW && t >= 0) ? tb[(size_t)t * GT::SW + w] : 0u;
+  }
+  s.cw = lane < GT::SW ? tb[(size_t)s.ply * GT::SW + lane] : 0u;
+}
+
 template <class GT, typename OutT>
-__device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input, const int g, const int lane) {
+__device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input, const int g, const int lane, const SelPre<GT> &s) {
   __shared__ uint32_t hist[8][GT::SW];
   __shared__ uint32_t cur[GT::SW];
-  const bool slotActive = v.active[g] != 0;  // one batch with the other per-slot words
-  const int ply = v.ply[g];
-  int pl = v.player[g];
-  const int used = v.edgeCnt[g];
-  int nParent = v.rootN[g];
+  const bool slotActive = s.active;
+  const int ply = s.ply;
+  int pl = s.player;
+  const int used = s.used;
+  int nParent = s.rootN;
   if (!slotActive) { if (lane == 0) v.evalFlag[g] = 0; return; }
-  const uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
   const size_t eb = (size_t)g * v.E;
 
   // A node's block is read with ALL its loads in flight at once (a lane owns records lane, lane + 64, ...; indices past
@@ -211,21 +232,14 @@ __device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input
       em[k] = v.edgeMeta[e];
     }
   };
-  constexpr int RW = (8 * GT::SW + 63) / 64;  // ring words per lane
-  uint32_t rw[RW];
-#pragma unroll
-  for (int k = 0; k < RW; ++k) {
-    const int i = lane + 64 * k, hk = i / GT::SW, w = i % GT::SW, t = ply - 7 + hk;
-    rw[k] = (i < 8 * GT::SW && t >= 0) ? tb[(size_t)t * GT::SW + w] : 0u;
-  }
-  const uint32_t cw = lane < GT::SW ? tb[(size_t)ply * GT::SW + lane] : 0u;
+  constexpr int RW = SelPre<GT>::RW;
   if (used > 0) fetch(0, GT::PMAX - ply);
 #pragma unroll
   for (int k = 0; k < RW; ++k) {
     const int i = lane + 64 * k;
-    if (i < 8 * GT::SW) hist[i / GT::SW][i % GT::SW] = rw[k];
+    if (i < 8 * GT::SW) hist[i / GT::SW][i % GT::SW] = s.rw[k];
   }
-  if (lane < GT::SW) cur[lane] = cw;
+  if (lane < GT::SW) cur[lane] = s.cw;
   __syncthreads();
 
   int head = 0, depth = 0, kind = KIND_EVAL, base = 0;
@@ -293,7 +307,15 @@ __device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input
 
 template <class GT, typename OutT>
 __global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
-  select_gather_body<GT, OutT>(v, nn_input, blockIdx.x, threadIdx.x);
+  const int g = blockIdx.x, lane = threadIdx.x;
+  SelPre<GT> s;
+  s.active = v.active[g] != 0;  // one batch
+  s.ply = v.ply[g];
+  s.player = v.player[g];
+  s.used = v.edgeCnt[g];
+  s.rootN = v.rootN[g];
+  sel_load_ring<GT>(v, g, lane, s);  // (all valid memory for an inactive slot too)
+  select_gather_body<GT, OutT>(v, nn_input, g, lane, s);
 }
 
 // Compact list of the slots whose leaf needs the network, in slot order: one workgroup; each thread owns a
@@ -331,9 +353,11 @@ __global__ __launch_bounds__(1024) void k_compact_leaves(View v, int per) {
 
 // ------------------------------------------------------------------------- expand + backup ----
 // MCTS._get_prior :180-192, MCTSNode.expand :43-57, MCTSNode.update :80-88, MCTS._bacaward :194-200.
-template <class GT>
+// PRE: also prepare the NEXT descent of the same slot (k_expand_select): its slot words ride with this body's first batch
+// (edge count and root visits are handed over as this body leaves them), its ring words with the second.
+template <class GT, bool PRE>
 __device__ __forceinline__ void expand_backup_body(const View &v, const float *logits, const float *values, const float *noise,
-                                                   const int g, const int lane) {
+                                                   const int g, const int lane, SelPre<GT> *sp) {
   const bool slotActive = v.active[g] != 0;  // tested after the batch below is on its way (all of it is valid memory)
   __shared__ uint32_t st[GT::SW];
   constexpr int A = GT::A, NI = (A + 63) / 64;
@@ -355,7 +379,15 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
   const int rootN = v.rootN[g];
   const double rootQ = v.rootQ[g];
   const int pth = lane < v.D ? path[lane] : 0;
+  if (PRE) {
+    sp->active = slotActive;
+    sp->ply = v.ply[g];
+    sp->player = v.player[g];
+    sp->used = used;    // (what the descent finds if this body leaves early on an error)
+    sp->rootN = rootN;
+  }
   if (!slotActive) return;
+  if (PRE) sel_load_ring<GT>(v, g, lane, *sp);  // on its way with the path records below
   const int depth = lf.x, kind = lf.y;
   // this lane's path edge (lane j owns path edge depth-1-j), fetched before the expansion's arithmetic
   const int pj = depth <= 64 ? __shfl(pth, max(depth - 1 - lane, 0), 64) : path[depth - 1 - lane];
@@ -424,6 +456,7 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
       }
       off += __popcll(bal[i]);
     }
+    if (PRE) sp->used = used + nLegal;
     if (lane == 0) {
       v.edgeCnt[g] = used + nLegal;
       // the leaf's own edge is path[depth-1] = lane 0's path edge: link it to its new block
@@ -468,6 +501,7 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
     }
     if (__popcll(fm) & 1) val = -val;
   }
+  if (PRE) sp->rootN = rootN + 1;
   if (lane == 0) {
     const int n = rootN + 1;
     v.rootN[g] = n;
@@ -478,7 +512,7 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
 template <class GT>
 __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logits, const float *values,
                                                       const float *noise) {
-  expand_backup_body<GT>(v, logits, values, noise, blockIdx.x, threadIdx.x);
+  expand_backup_body<GT, false>(v, logits, values, noise, blockIdx.x, threadIdx.x, nullptr);
 }
 
 // The end of simulation i and the beginning of simulation i+1 of the same tree in one launch (the search loop
@@ -488,9 +522,10 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
 template <class GT, typename OutT>
 __global__ __launch_bounds__(64) void k_expand_select(View v, const float *logits, const float *values, const float *noise,
                                                       OutT *nn_input) {
-  expand_backup_body<GT>(v, logits, values, noise, blockIdx.x, threadIdx.x);
+  SelPre<GT> s;
+  expand_backup_body<GT, true>(v, logits, values, noise, blockIdx.x, threadIdx.x, &s);
   __syncthreads();
-  select_gather_body<GT, OutT>(v, nn_input, blockIdx.x, threadIdx.x);
+  select_gather_body<GT, OutT>(v, nn_input, blockIdx.x, threadIdx.x, s);
 }
 
 // ------------------------------------------------------------------------- root policy --------
