@@ -134,6 +134,8 @@ def main():
                     "(what the small, launch-bound games want); the per-kernel HIP-event times then come from one eager probe "
                     "step run after the timed region.  0 (default): eager launches, events inside the timed region")
     ap.add_argument("--preroll", type=int, default=96, help="cheap 2-sim move rounds that stagger game ages")
+    ap.add_argument("--game-probe", type=int, default=1024, help="games played start to finish (full search, outside the timed "
+                    "region, rank 0) to measure the mean game length that converts plies/s into games/s; 0 = skip")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the "
@@ -152,7 +154,7 @@ def main():
     import torch.distributed as dist
 
     from alphazero_amd import Engine
-    from alphazero_amd.arena import SelfPlayRunner, reference_tao
+    from alphazero_amd.arena import END_TEMPERATURE, START_TEMPERATURE, TEMPERATURE_DECAY, SelfPlayRunner, reference_tao
     from alphazero_amd.samples import HostSampleRing, WeightPublisher
 
     torch.cuda.set_device(local_rank)
@@ -190,34 +192,53 @@ def main():
 
     copy_stream = torch.cuda.Stream(dev)
     games_started = slots
-    inv_tao_h = torch.tensor([1.0 / reference_tao(0)] * slots, dtype=torch.float32)
+    inv_tao_h = torch.tensor([1.0 / reference_tao(0)] * slots, dtype=torch.float32).pin_memory()
     inv_tao = inv_tao_h.to(dev)
     finished_games = 0
     finished_plies = 0
 
+    # Samples leave the GPU as int8 planes (+-1 / 0 are exact) + f32 pi + z: a quarter of the f32 bytes over PCIe (the
+    # D2H runs as a copy kernel on this stack and slows the search kernels it overlaps with).  The f32 ring rows are
+    # written by the host from the pinned staging buffers one move later, while the GPU runs the next search.
+    pending = []
+
+    def finalize_pending():
+        while pending:
+            ev, s8_h, pis_h, zs_h = pending.pop(0)
+            ev.synchronize()
+            ring.put_batch(s8_h, pis_h, zs_h)  # copy_ converts int8 -> f32 into the ring
+
     def collect(done):
         """emit + D2H the samples of the games that just ended, restart their slots"""
         nonlocal games_started, finished_games, finished_plies
-        done_h = done.cpu()
-        idx = torch.nonzero(done_h).reshape(-1)
+        plies, _, _, _ = eng.game_info()
+        both = torch.stack((done.to(torch.int32), plies)).cpu()  # the move's one host sync
+        idx = torch.nonzero(both[0]).reshape(-1)
         if idx.numel() == 0:
             return
-        plies, _, _, _ = eng.game_info()
-        plies_h = plies.cpu()[idx]
+        plies_h = both[1][idx]
         states, pis, zs, _ = eng.emit_samples(idx.to(torch.int32), plies_h)
-        # the D2H of the samples runs on a side stream, under the next move's search
+        eng.reset_games(done)
+        s8 = states.to(torch.int8)
         copy_stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(copy_stream):
-            ring.put_batch(states, pis, zs)
-            for t in (states, pis, zs):
+            staged = []
+            for t in (s8, pis, zs):
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
                 t.record_stream(copy_stream)
-        finished_games += int(idx.numel())
+                staged.append(h)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        pending.append((ev, *staged))
+        nf = int(idx.numel())
+        finished_games += nf
         finished_plies += int(plies_h.sum())
-        for s in idx.tolist():  # per-slot temperature schedule restarts with the new game
-            inv_tao_h[s] = 1.0 / reference_tao(games_started // slots)
-            games_started += 1
+        # per-slot temperature schedule restarts with the new game (reference_tao, vectorised)
+        k = (games_started + torch.arange(nf)) // slots
+        inv_tao_h[idx] = (1.0 / torch.clamp(START_TEMPERATURE * TEMPERATURE_DECAY ** k.double(), min=END_TEMPERATURE)).float()
+        games_started += nf
         inv_tao.copy_(inv_tao_h, non_blocking=True)
-        eng.reset_games(done)
 
     # --- pre-roll: stagger game ages so that games finish at a steady rate during the timed steps
     if args.preroll > 0:
@@ -268,10 +289,12 @@ def main():
         if publisher.publish(force=args.force_dist) and run.fused is not None:  # learner -> self-play weight push (RCCL broadcast; no-op at N = 1)
             run.fused.refresh()  # re-fold BatchNorm / re-pack the published weights for the fused tower
         done = timed_round() if (timed and not args.graph) else run.move_round(inv_tao)[1]
+        finalize_pending()  # the previous move's samples -> the host ring, under the search just queued
         collect(done)
 
     for _ in range(args.warmup):
         step(False)
+    finalize_pending()
     eng.check()
     eng.reset_stats()
     finished_games = finished_plies = 0
@@ -282,6 +305,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    finalize_pending()  # the last move's samples belong to the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -306,6 +330,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
     total_sims, total_games, total_plies = float(tt[1]), float(tt[2]), float(tt[3])
+
+    # Games per second.  The games that end inside the timed steps were aged by the pre-roll's cheap moves, so their count
+    # says nothing about a steady state.  games/s = plies/s (measured above) / mean plies of a game played start to finish
+    # with the full search: measured here on a small population, outside the timed region.
+    game_len = None
+    if rank == 0 and args.game_probe > 0 and args.evaluator != "hash":
+        pe = Engine(game, args.game_probe, sims, board_size=n, nn_dtype=tdtype, device=dev)
+        pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=(args.evaluator == "fused"), use_graph=bool(args.graph))
+        pit = torch.full((args.game_probe,), 1.0 / reference_tao(0), device=dev)
+        lengths, moves, tp0 = [], 0, time.perf_counter()
+        while len(lengths) < args.game_probe and moves <= d.max_plies and time.perf_counter() - tp0 < 60.0:
+            done_h = pr.move_round(pit)[1].cpu().bool()
+            moves += 1
+            if bool(done_h.any()):
+                lengths += pe.game_info()[0].cpu()[done_h].tolist()
+        pe.check()
+        if lengths:
+            game_len = {"mean_plies": sum(lengths) / len(lengths), "games": len(lengths), "of": args.game_probe,
+                        "seconds": time.perf_counter() - tp0,
+                        "how": f"{args.game_probe} games played start to finish with the same network and {sims} sims/move, tao = 1"}
+        del pr, pe
 
     # what an empty event pair reads on this stream (record -> record): subtracted from every bracketed launch
     empty = []
@@ -384,8 +429,12 @@ def main():
             "config": {"workload": f"{args.workload}: {sims} sims/move, {slots} concurrent games per GPU, "
                                    f"evaluator={args.evaluator}, one step = one self-play move of every game",
                        "slots_per_gpu": slots, "sims_per_move": sims, "parallelism": f"games sharded x{world}, no data-path collective"},
-            "games_per_sec": total_games / elapsed, "plies_per_sec": slots * world * args.steps / elapsed,
-            "mean_plies_per_finished_game": (total_plies / total_games) if total_games else None,
+            "plies_per_sec": slots * world * args.steps / elapsed,
+            "games_per_sec": (slots * world * args.steps / elapsed / game_len["mean_plies"]) if game_len else None,
+            "games_per_sec_note": "plies_per_sec / game_length.mean_plies (steady state); the games that ended inside the timed "
+                                  "steps had been aged by the pre-roll and are only counted in finished_in_window",
+            "game_length": game_len,
+            "finished_in_window": {"games": total_games, "mean_plies": (total_plies / total_games) if total_games else None},
             "roofline": roofline,
             "roofline_tree": tree_roofline,
             "tree_kernels": {"k_expand_select": {"ms": tree_ms, "bytes": sel_bytes + exp_bytes,
