@@ -1095,6 +1095,31 @@ int az_emit_samples(az_engine *e, const int32_t *slots_dev, const int32_t *offse
   return launch_check(e, "k_emit_samples");
 }
 
+// Device -> pinned host copy by a handful of workgroups.  A D2H hipMemcpyAsync runs as a copy kernel on this stack
+// (__amd_rocclr_copyBuffer) that fills the chip: measured here, the search kernels it overlaps with ran 2-30x slower
+// for the 5-10 ms the samples of a move take.  The copy is PCIe bound, so 16 workgroups keep the link busy and leave
+// 240 CUs to the search.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+__global__ __launch_bounds__(256) void k_copy_to_host(const u32x4_t *__restrict__ src, u32x4_t *__restrict__ dst, size_t n16,
+                                                      const uint8_t *__restrict__ src_tail, uint8_t *__restrict__ dst_tail, int tail) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+int az_copy_to_host(void *dst_pinned_host, const void *src_dev, uint64_t bytes, int32_t n_workgroups, void *stream) {
+  if (!dst_pinned_host || !src_dev || n_workgroups < 1 || n_workgroups > 1024) return AZ_EINVAL;
+  if (((uintptr_t)dst_pinned_host | (uintptr_t)src_dev) & 15u) return AZ_EINVAL;
+  if (bytes == 0) return AZ_OK;
+  void *dst_dev = nullptr;  // the device's address of the pinned allocation (the same value under unified addressing)
+  if (hipHostGetDevicePointer(&dst_dev, dst_pinned_host, 0) != hipSuccess || dst_dev == nullptr) { (void)hipGetLastError(); return AZ_EINVAL; }
+  const size_t n16 = bytes / 16;
+  const int tail = (int)(bytes % 16);
+  hipLaunchKernelGGL(k_copy_to_host, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4_t *)src_dev, (u32x4_t *)dst_dev, n16,
+                     (const uint8_t *)src_dev + n16 * 16, (uint8_t *)dst_dev + n16 * 16, tail);
+  return hipGetLastError() == hipSuccess ? AZ_OK : AZ_EHIP;
+}
+
 static void dab_rot(int &r, int &c, int k, int n) {  // examples/dots_and_boxes/game.py:305-313 on an n x n grid
   for (int q = 0; q < (k & 3); ++q) { const int nr = n - 1 - c, nc = r; r = nr; c = nc; }
 }

@@ -40,7 +40,7 @@ class AzStats(C.Structure):
 EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check", "az_reset_games",
            "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_expand_select", "az_root_policy",
            "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
-           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_heads_forward", "az_heads_feat_stride", "az_augment_samples", "az_leaf_buffers", "az_compact_leaves"]
+           "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_heads_forward", "az_heads_feat_stride", "az_augment_samples", "az_leaf_buffers", "az_compact_leaves", "az_copy_to_host"]
 
 _lib = None
 
@@ -83,6 +83,7 @@ def load_library() -> C.CDLL:
     lib.az_heads_feat_stride.argtypes = [C.c_int32]
     lib.az_heads_feat_stride.restype = C.c_int32
     lib.az_compact_leaves.argtypes = [vp, vp]
+    lib.az_copy_to_host.argtypes = [vp, vp, C.c_uint64, C.c_int32, vp]
     lib.az_leaf_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
@@ -91,6 +92,24 @@ def load_library() -> C.CDLL:
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
+
+
+def copy_to_host(dst: torch.Tensor, src: torch.Tensor, workgroups: int = 16) -> None:
+    """src (device, contiguous) -> dst (pinned host, contiguous, same dtype and shape) on torch's current stream, by a few
+    workgroups (az_copy_to_host): unlike a D2H ``copy_`` it leaves the chip to the kernels it overlaps with.  The data is
+    valid once the stream has been synchronised (or an event recorded after the call has completed)."""
+    if dst.dtype != src.dtype or dst.numel() != src.numel():
+        raise EngineError("copy_to_host: dtype / size mismatch")
+    if src.numel() == 0:
+        return
+    if not (dst.is_pinned() and dst.is_contiguous() and src.is_contiguous() and src.is_cuda):
+        raise EngineError("copy_to_host: dst must be a contiguous pinned host tensor, src a contiguous device tensor")
+    lib = load_library()
+    with torch.cuda.device(src.device):
+        st = C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+        rc = lib.az_copy_to_host(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), src.numel() * src.element_size(), workgroups, st)
+    if rc != 0:
+        raise EngineError(f"az_copy_to_host failed ({rc})")
 
 
 class EngineError(RuntimeError):

@@ -155,6 +155,7 @@ def main():
 
     from alphazero_amd import Engine
     from alphazero_amd.arena import END_TEMPERATURE, START_TEMPERATURE, TEMPERATURE_DECAY, SelfPlayRunner, reference_tao
+    from alphazero_amd.engine import copy_to_host
     from alphazero_amd.samples import HostSampleRing, WeightPublisher
 
     torch.cuda.set_device(local_rank)
@@ -225,7 +226,7 @@ def main():
             staged = []
             for t in (s8, pis, zs):
                 h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-                h.copy_(t, non_blocking=True)
+                copy_to_host(h, t)  # 16 workgroups: a D2H copy_ is a chip-wide copy kernel here and stalls the search
                 t.record_stream(copy_stream)
                 staged.append(h)
             ev = torch.cuda.Event()

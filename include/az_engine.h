@@ -165,6 +165,13 @@ int az_game_info(az_engine *e, int32_t *plies_dev, int32_t *player_dev, uint8_t 
 int az_emit_samples(az_engine *e, const int32_t *slots_dev, const int32_t *offsets_dev, int32_t n_games,
                     float *states_dev, float *pis_dev, float *z_dev, void *stream);
 
+/* Device -> pinned host copy of `bytes` bytes by n_workgroups (1..1024; 16 is enough for the PCIe link) workgroups on
+ * `stream`: how finished games' samples reach the host pool (training/self_play.py:124-126 hands the pool
+ * `.detach().clone()`d CPU tensors) without a chip-wide copy kernel slowing the search it overlaps with.
+ * dst_pinned_host: hipHostMalloc'ed / torch pin_memory() memory; both pointers 16-byte aligned.  The data is
+ * visible to the host once the stream has reached this point (event or stream synchronize). */
+int az_copy_to_host(void *dst_pinned_host, const void *src_dev, uint64_t bytes, int32_t n_workgroups, void *stream);
+
 /* the 8-fold symmetry expansion the reference's pools apply on every put
  * (utils/experience_pool.py:27-31 -> game_cls.get_enhanced_data: utils/data_enhancer.py:13-70;
  * examples/dots_and_boxes/game.py:158-320), on the device: sample i (rows of states_dev (n, C_in*H*W),

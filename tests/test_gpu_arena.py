@@ -195,3 +195,18 @@ def test_self_play_train_loop_runs_and_learns():
 
     losses = [loop.learner.step(Fixed(), 256)[0] for _ in range(40)]
     assert losses[-1] < 0.8 * losses[0]
+
+
+def test_copy_to_host_moves_every_byte():
+    """az_copy_to_host (the few-workgroup D2H the sample path uses) == Tensor.cpu(), odd sizes included."""
+    from alphazero_amd.engine import EngineError, copy_to_host
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n, dt in ((1, torch.int8), (15, torch.int8), (16, torch.int8), (2025 * 37 + 5, torch.int8), (225 * 1001, torch.float32), (0, torch.float32)):
+        src = torch.randint(-100, 100, (n,), device="cuda", generator=g).to(dt)
+        dst = torch.zeros(n, dtype=dt).pin_memory()
+        copy_to_host(dst, src)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src.cpu())
+    with pytest.raises(EngineError):
+        copy_to_host(torch.zeros(4), torch.zeros(4, device="cuda"))  # not pinned
