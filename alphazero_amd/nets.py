@@ -3,8 +3,9 @@
     forward(x: (B, C_in, H, W) f32) -> (logits (B, A), value (B, 1) in [-1, 1])
            = policy_head(shared_layers(x)), value_head(shared_layers(x))
 
-The dense forward stays in PyTorch-ROCm (MFMA via MIOpen/hipBLASLt); the engine only needs the
-contract.  Any reference ``BaseModel`` subclass works unchanged.  The nets here exist because the
+The engine only needs the contract: any reference ``BaseModel`` subclass works unchanged through its own
+PyTorch-ROCm forward; the GomokuNet family (64 or 128 channels) is additionally evaluated by the hand-written
+fused MFMA tower (alphazero_amd.fused / csrc/az_tower.hip).  The nets here exist because the
 reference does not travel to the GPU box: they rebuild the reference's example architectures
 (examples/tictactoe/model.py, examples/dots_and_boxes/model.py, examples/gomoku/model.py) with the
 SAME parameter names, so a reference checkpoint (result/models/*/last_model.pth) loads with
