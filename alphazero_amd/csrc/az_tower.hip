@@ -118,6 +118,9 @@ __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
 #ifndef AZ_TOWER9_ST
 #define AZ_TOWER9_ST 1  // 9x9 (3 boards per workgroup): per-tap staging keeps two workgroups within a CU's 160 KiB of LDS
 #endif
+#ifndef AZ_TOWER_EARLY_BARRIER
+#define AZ_TOWER_EARLY_BARRIER 1
+#endif
 #ifndef AZ_TOWER_WAVES_PER_SIMD
 #define AZ_TOWER_WAVES_PER_SIMD 2
 #endif
@@ -176,6 +179,9 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
   constexpr int NSTAGE = 9 / ST, STAGE_BYTES = BS, NK = ST * KS;
   static_assert(ST * TB <= BS && STN * KSN * 2 * KB <= BS, "a stage fits its buffer");
   constexpr bool XPF = (NK % 2 == 0) && NSTAGE > 1;  // cross-barrier prefetch needs the last k-step in register set 1
+  // 1: the 128-channel geometry only (8 waves in lockstep, 9 stages per layer: -2.4 %; at 64 channels it measured +-0 on
+  // 15x15, three spilled registers, and +0.9 % on 9x9: there the partner workgroup already fills the gap); 2: all
+  constexpr bool EARLY = AZ_TOWER_EARLY_BARRIER == 2 || (AZ_TOWER_EARLY_BARRIER == 1 && C == 128);
   const int h = lane >> 5, r = lane & 31, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cot0 = C > 64 ? (wave >> 2) * 2 : 0;  // this wave's first 32-channel output tile
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
@@ -209,17 +215,19 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
 #pragma unroll 1
   for (int sg = 0; sg < NSTAGE; ++sg) {
     const uint32_t wa32 = (uint32_t)(uintptr_t)(wbuf + ((buf + sg) & 1) * STAGE_BYTES + h * KB + (cot0 * 32 + r) * 16);
-    auto load_a = [&](int i, int s) {
+    const uint32_t wa32n = (uint32_t)(uintptr_t)(wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES + h * KB + (cot0 * 32 + r) * 16);
+    auto load_a_at = [&](uint32_t base, int i, int s) {
       const int j = i / KS, ks = i % KS;
 #if AZ_TOWER_ABLATE == 2 || AZ_TOWER_ABLATE == 4
       if (i < 2) fa[s][0] = fa[s][1] = (bf16x8)(__bf16)(AZ_TOWER_ABLATE == 2 ? 1.0f : 0.0f);
       return;
 #endif
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][0]) : "v"(wa32), "i"(j * TB + ks * 2 * KB));
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][1]) : "v"(wa32), "i"(j * TB + ks * 2 * KB + 512));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][0]) : "v"(base), "i"(j * TB + ks * 2 * KB));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][1]) : "v"(base), "i"(j * TB + ks * 2 * KB + 512));
     };
+    auto load_a = [&](int i, int s) { load_a_at(wa32, i, s); };
     if (!XPF) { if (sg > 0) bases(sg); load_b(0, 0); }
-    load_a(0, 0);
+    if (!(XPF && EARLY) || sg == 0) load_a(0, 0);  // (EARLY: a later stage's first fragments were requested before the previous stage's last MFMAs)
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       if (i + 1 < NK) {
@@ -227,6 +235,22 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
         load_b(i + 1, (i + 1) & 1);
         if (NPT == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // step i's reads have returned
         else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      } else if (XPF && EARLY) {
+        // The stage barrier comes BEFORE the last k-step's MFMAs: this wave's reads of the stage have all returned and
+        // its share of the next stage's weights has landed, so after the barrier the next stage's first fragments (A and
+        // B) are requested and travel under those MFMAs -- no stage starts with an exposed LDS round trip.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (sg + 1 < NSTAGE) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          __builtin_amdgcn_sched_barrier(0);
+          bases(sg + 1);
+          load_b(0, 0);
+          load_a_at(wa32n, 0, 0);
+        } else {
+          __syncthreads();  // the layer's last stage: every wave has finished reading act -> the epilogues may overwrite it
+        }
       } else if (XPF && sg + 1 < NSTAGE) {
         bases(sg + 1);  // the next stage's first activation fragments: in flight across the stage barrier
         load_b(0, 0);
@@ -256,6 +280,7 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
 #if AZ_TOWER_STAMP
     const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
+    if (XPF && EARLY) continue;  // (its barrier stands before the stage's last MFMAs)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next stage has landed
     if (XPF && sg + 1 < NSTAGE) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // compiler-level ordering only matters for the DMA'd bytes:
