@@ -498,13 +498,13 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) voi
   constexpr int BOARD_BYTES = 8 * SWB * 4;
   // Groups of BPW boards are handed out by a ticket counter, not by block index: the two workgroups that share a CU
   // do not run at the same speed (the MFMA pipe favours the older one's waves: measured 818 vs 1,008 us for 32 boards
-  // each), so a fixed split leaves every CU half empty for the last fifth of the launch.  tickets[0] = next group,
+  // each), so a fixed split leaves every CU half empty for the last fifth of the launch.  tickets[0] = next group - gridDim.x (the first gridDim.x groups go by block index),
   // tickets[1] = workgroups that have drawn a ticket past the end; the last of them zeroes both for the next launch.
   // Wave 0 runs the protocol one group ahead, in three steps spread over the current group's tower so that none of
   // them is waited for: draw (atomic), look the slots up in the list, start the DMA of the packed input.
   int tk_draw = 0, tk_next = 0, sl_next = -1;  // wave 0: the next group's ticket; lane b < BPW: its b-th slot
   auto draw = [&]() {  // step 1: lane 0's returning atomic; nothing reads the result before step 2
-    if (wave == 0 && lane == 0) tk_draw = (int)atomicAdd(&tickets[0], 1u);
+    if (wave == 0 && lane == 0) tk_draw = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));
   };
   auto lookup = [&]() {  // step 2 (uses the ticket)
     if (wave != 0) return;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) voi
       // (7 % of the single-board groups: terminal leaves) costs one more draw, waited for on the spot
       if (sl_next >= 0 && flags[sl_next] == 0) sl_next = -1;
       if (__ballot(sl_next >= 0) != 0ull) break;
-      tk_next = __builtin_amdgcn_readfirstlane(lane == 0 ? (int)atomicAdd(&tickets[0], 1u) : 0);
+      tk_next = __builtin_amdgcn_readfirstlane(lane == 0 ? (int)(gridDim.x + atomicAdd(&tickets[0], 1u)) : 0);
     }
   };
   auto fetch = [&](int which) {  // step 3 (uses the slots): slots + ticket by ds_write, ring words + players by LDS-DMA
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) voi
   auto bias_step = [&]() { bslot = bslot == 2 ? 0 : bslot + 1; };
   // prologue: the stem's first weight stage and the first group's input
   stage_w<1, ST0, NW, C / 64>(w0, wbuf, wave, lane);
-  draw();
+  tk_draw = (int)blockIdx.x;  // the first group needs no atomic: tickets 0 .. gridDim.x-1 are the block indices, the counter hands out the rest
   lookup();
   fetch(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
