@@ -67,7 +67,7 @@ def test_packed_leaf_batch_equals_dense_planes(board, ch):
     from alphazero_amd.nets import GomokuNet
 
     torch.manual_seed(0)
-    G, sims = 200, 12
+    G, sims = (1500 if (board, ch) == (15, 64) else 200), 12  # 1500: several tickets per workgroup (512 workgroups), flags included
     net = _randomised(GomokuNet(board, ch, 2)).eval().cuda()
     ev = FusedTowerEvaluator(net)
     eng = Engine(2, G, sims, board_size=board, nn_dtype=torch.bfloat16, device="cuda:0")
