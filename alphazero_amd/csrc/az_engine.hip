@@ -40,12 +40,12 @@
 #include <vector>
 
 #include "../../include/az_engine.h"
-#include "az_games.cuh"
+#include "az_games.hip.h"
 
 namespace az {
 
 enum : int { KIND_EVAL = 0, KIND_TERMINAL = 1 };
-enum : int { ERR_EDGE_CAP = 1, ERR_NODE_CAP = 2, ERR_DEPTH_CAP = 4, ERR_ILLEGAL = 8, ERR_NO_ROOT = 16 };
+enum : int { ERR_EDGE_CAP = 1, ERR_NODE_CAP = 2, ERR_DEPTH_CAP = 4, ERR_ILLEGAL = 8, ERR_NO_ROOT = 16, ERR_EMIT_SETPOS = 32 };
 
 struct View {  // kernel argument: raw device pointers + sizes
   int G, E, D;
@@ -66,6 +66,7 @@ struct View {  // kernel argument: raw device pointers + sizes
   int8_t *trajPlayer;
   uint16_t *trajVisits;
   int32_t *ply;
+  int32_t *startPly;   // [G] 0 for a game started by az_reset_games; the root's ply for a slot loaded by az_set_position
   int32_t *player;
   uint8_t *active;
   float *result;
@@ -644,6 +645,10 @@ __global__ __launch_bounds__(64) void k_emit_samples(View v, const int32_t *slot
   const int g = slots[blockIdx.x], j = blockIdx.y, lane = threadIdx.x;
   constexpr int A = GT::A;
   if (g < 0 || g >= v.G) return;
+  if (v.startPly[g] != 0) {  // a slot loaded by az_set_position has no trajectory before its root: nothing to emit
+    if (j == 0 && lane == 0) atomicOr(v.err, ERR_EMIT_SETPOS);
+    return;
+  }
   const int T = v.ply[g];
   if (j >= T) return;
   const int t = T - 1 - j;
@@ -724,6 +729,7 @@ __global__ void k_reset_games(View v, const uint8_t *mask) {
   uint32_t *tb = v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW;
   for (int w = 0; w < GT::SW; ++w) tb[w] = 0u;
   v.ply[g] = 0;
+  v.startPly[g] = 0;
   v.player[g] = 1;
   v.active[g] = 1;
   v.result[g] = 0.0f;
@@ -789,6 +795,17 @@ struct az_engine {
 };
 
 static std::string g_create_err;
+
+// Every entry point runs with the engine's GPU current, whatever device the calling thread had selected (a process with
+// several engines, or a caller that never called hipSetDevice), and puts the caller's device back on the way out.
+struct DeviceGuard {
+  int back = -1;
+  explicit DeviceGuard(int want) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != want && hipSetDevice(want) == hipSuccess) back = cur;
+  }
+  ~DeviceGuard() { if (back >= 0) (void)hipSetDevice(back); }
+};
 
 #define AZ_HIP(call)                                                                        \
   do {                                                                                      \
@@ -899,6 +916,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   v.trajPlayer = (int8_t *)alloc(G * (size_t)(d.max_plies + 1));
   v.trajVisits = (uint16_t *)alloc(G * (size_t)d.max_plies * A * sizeof(uint16_t));
   v.ply = (int32_t *)alloc(G * sizeof(int32_t));
+  v.startPly = (int32_t *)alloc(G * sizeof(int32_t));
   v.player = (int32_t *)alloc(G * sizeof(int32_t));
   v.active = (uint8_t *)alloc(G);
   v.result = (float *)alloc(G * sizeof(float));
@@ -945,6 +963,7 @@ int az_get_dims(const az_engine *e, az_dims *out) {
 
 int az_check(az_engine *e, void *stream) {
   if (!e) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   int32_t flag = 0;
   AZ_HIP(hipMemcpyAsync(&flag, e->v.err, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream));
   AZ_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -954,6 +973,7 @@ int az_check(az_engine *e, void *stream) {
     if (flag & ERR_DEPTH_CAP) e->err += " path deeper than depth_cap";
     if (flag & ERR_ILLEGAL) e->err += " illegal move";
     if (flag & ERR_NO_ROOT) e->err += " root not expanded / no child to select";
+    if (flag & ERR_EMIT_SETPOS) e->err += " az_emit_samples on a slot loaded by az_set_position (no trajectory before its root)";
     return AZ_EDEVICE;
   }
   return AZ_OK;
@@ -961,6 +981,7 @@ int az_check(az_engine *e, void *stream) {
 
 int az_reset_games(az_engine *e, const uint8_t *mask_dev, void *stream) {
   if (!e) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   const int G = e->v.G;
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_reset_games<GT>), dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->v, mask_dev));
   return launch_check(e, "k_reset_games");
@@ -968,6 +989,7 @@ int az_reset_games(az_engine *e, const uint8_t *mask_dev, void *stream) {
 
 int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32_t root_player, void *stream) {
   if (!e || !history_host) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   if (slot < 0 || slot >= e->v.G) { e->err = "slot out of range"; return AZ_EINVAL; }
   if (root_player != 1 && root_player != -1) { e->err = "root_player must be +1 or -1"; return AZ_EINVAL; }
   const az_dims &d = e->dims;
@@ -981,6 +1003,11 @@ int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32
   }
   const int ply = nm[7];
   if (ply >= d.max_plies) { e->err = "position has no move left"; return AZ_EINVAL; }
+  {  // a root that is already won is terminal: the reference evaluates it by rule (core/MCTS_alphazero.py:157-158), there is no search
+    bool won = false;
+    AZ_DISPATCH(e, won = GT::host_won(words.data() + (size_t)7 * SW));
+    if (won) { e->err = "position is already terminal (a side has won)"; return AZ_EINVAL; }
+  }
   // entries older than the start of the game must be the initial (empty) state
   for (int k = 0; k < 8; ++k) {
     const int t = ply - 7 + k;
@@ -996,16 +1023,21 @@ int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32
   const int32_t one_ply = ply, one_player = root_player;
   const uint8_t act = 1;
   const int32_t zero = 0;
+  const double zero_q = 0.0;
   AZ_HIP(hipMemcpyAsync(e->v.ply + slot, &one_ply, sizeof(int32_t), hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.player + slot, &one_player, sizeof(int32_t), hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.active + slot, &act, 1, hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.edgeCnt + slot, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  AZ_HIP(hipMemcpyAsync(e->v.rootN + slot, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  AZ_HIP(hipMemcpyAsync(e->v.rootQ + slot, &zero_q, sizeof(double), hipMemcpyHostToDevice, s));
+  AZ_HIP(hipMemcpyAsync(e->v.startPly + slot, &one_ply, sizeof(int32_t), hipMemcpyHostToDevice, s));
   AZ_HIP(hipStreamSynchronize(s));  // host staging buffers die here
   return AZ_OK;
 }
 
 int az_begin_search(az_engine *e, void *stream) {
   if (!e) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   const int G = e->v.G;
   hipLaunchKernelGGL(k_begin_search, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->v);
   return launch_check(e, "k_begin_search");
@@ -1024,6 +1056,7 @@ int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf
 
 int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
   if (!e) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   const dim3 grid(e->v.G), block(64);
   hipStream_t s = (hipStream_t)stream;
   switch (e->cfg.nn_dtype) {
@@ -1036,12 +1069,14 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
 
 int az_compact_leaves(az_engine *e, void *stream) {
   if (!e) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   hipLaunchKernelGGL(k_compact_leaves, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->v, ((e->v.G + 16383) / 16384) * 16);
   return launch_check(e, "k_compact_leaves");
 }
 
 int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev, void *stream) {
   if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_backup<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, logits_dev, values_dev, noise_dev));
   return launch_check(e, "k_expand_backup");
 }
@@ -1049,6 +1084,7 @@ int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_
 int az_expand_select(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev, void *nn_input_dev,
                      void *stream) {
   if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   const dim3 grid(e->v.G), block(64);
   hipStream_t s = (hipStream_t)stream;
   switch (e->cfg.nn_dtype) {
@@ -1061,12 +1097,14 @@ int az_expand_select(az_engine *e, const float *logits_dev, const float *values_
 
 int az_root_policy(az_engine *e, float *pi_dev, int32_t *visits_dev, double *child_q_dev, float *root_prior_dev, void *stream) {
   if (!e) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_root_policy<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, pi_dev, visits_dev, child_q_dev, root_prior_dev));
   return launch_check(e, "k_root_policy");
 }
 
 int az_root_nn_state(az_engine *e, float *nn_state_dev, void *stream) {
   if (!e || !nn_state_dev) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_root_nn_state<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, nn_state_dev));
   return launch_check(e, "k_root_nn_state");
 }
@@ -1074,6 +1112,7 @@ int az_root_nn_state(az_engine *e, float *nn_state_dev, void *stream) {
 int az_play_moves(az_engine *e, const float *inv_tao_dev, const float *expo_dev, const int32_t *forced_actions_dev,
                   int32_t *actions_dev, uint8_t *done_dev, void *stream) {
   if (!e || !inv_tao_dev || !expo_dev) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_play_moves<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, inv_tao_dev, expo_dev,
                                     forced_actions_dev, actions_dev, done_dev));
   return launch_check(e, "k_play_moves");
@@ -1081,6 +1120,7 @@ int az_play_moves(az_engine *e, const float *inv_tao_dev, const float *expo_dev,
 
 int az_game_info(az_engine *e, int32_t *plies_dev, int32_t *player_dev, uint8_t *active_dev, float *result_dev, void *stream) {
   if (!e) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   const int G = e->v.G;
   hipLaunchKernelGGL(k_game_info, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->v, plies_dev, player_dev, active_dev, result_dev);
   return launch_check(e, "k_game_info");
@@ -1089,6 +1129,7 @@ int az_game_info(az_engine *e, int32_t *plies_dev, int32_t *player_dev, uint8_t 
 int az_emit_samples(az_engine *e, const int32_t *slots_dev, const int32_t *offsets_dev, int32_t n_games, float *states_dev,
                     float *pis_dev, float *z_dev, void *stream) {
   if (!e || !slots_dev || !offsets_dev || !states_dev || !pis_dev || !z_dev || n_games < 0) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   if (n_games == 0) return AZ_OK;
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_emit_samples<GT>), dim3(n_games, e->dims.max_plies), dim3(64), 0, (hipStream_t)stream, e->v,
                                     slots_dev, offsets_dev, states_dev, pis_dev, z_dev));
@@ -1152,6 +1193,7 @@ int az_augment_samples(az_engine *e, int32_t n, const float *states_dev, const f
                        float *out_states_dev, float *out_pis_dev, float *out_z_dev, int64_t ring_capacity,
                        int64_t ring_write_idx, void *stream) {
   if (!e || !states_dev || !pis_dev || !z_dev || !out_states_dev || !out_pis_dev || !out_z_dev || n < 0) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   if (ring_capacity < 0 || ring_write_idx < 0 || (ring_capacity > 0 && ring_capacity < 8)) { e->err = "bad ring arguments"; return AZ_EINVAL; }
   if (n == 0) return AZ_OK;
   static const AugTables tb = make_aug_tables();
@@ -1162,6 +1204,7 @@ int az_augment_samples(az_engine *e, int32_t n, const float *states_dev, const f
 
 int az_read_stats(az_engine *e, az_stats *out, void *stream) {
   if (!e || !out) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   const size_t n = (size_t)e->v.G * 6;
   std::vector<unsigned long long> h(n);
   AZ_HIP(hipMemcpyAsync(h.data(), e->v.stat, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1176,12 +1219,14 @@ int az_read_stats(az_engine *e, az_stats *out, void *stream) {
 
 int az_reset_stats(az_engine *e, void *stream) {
   if (!e) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   AZ_HIP(hipMemsetAsync(e->v.stat, 0, (size_t)e->v.G * 6 * sizeof(unsigned long long), (hipStream_t)stream));
   return AZ_OK;
 }
 
 int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *logits_dev, float *values_dev, void *stream) {
   if (!e || !nn_input_dev || !logits_dev || !values_dev) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
   const dim3 grid(e->v.G), block(64);
   hipStream_t s = (hipStream_t)stream;
   const int A = e->dims.n_action;

@@ -1,4 +1,4 @@
-// az_games.cuh -- bitboard rules of the three games, for one wavefront per position.
+// az_games.hip.h -- bitboard rules of the three games, for one wavefront per position.
 //
 // A state is SW u32 words kept in LDS.  Every function is called by all 64 lanes of the wave with
 // wave-uniform arguments unless it says "per lane".  apply() contains workgroup barriers, so it is
@@ -58,6 +58,13 @@ struct TicTacToe {
       else if (st[i] != 0.0f) return false;
     }
     return true;
+  }
+  // host: has either side already completed a line?  (az_set_position refuses such roots: the reference evaluates them by rule)
+  __host__ static bool host_won(const uint32_t *w) {
+    const uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
+    for (int i = 0; i < 8; ++i)
+      if ((w[0] & L[i]) == L[i] || ((w[0] >> 9) & L[i]) == L[i]) return true;
+    return false;
   }
 };
 
@@ -137,6 +144,7 @@ struct Dab {
       }
     return true;
   }
+  __host__ static bool host_won(const uint32_t *) { return false; }  // terminal only when all 24 edges are drawn (ply == PMAX)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -193,6 +201,25 @@ struct Gomoku {
       else if (st[i] != 0.0f) return false;
     }
     return true;
+  }
+  __host__ static bool host_won(const uint32_t *w) {  // five (or more) in a row of either colour: game.py:62-89
+    const int DR[4] = {0, 1, 1, 1}, DC[4] = {1, 0, 1, -1};
+    for (int side = 0; side < 2; ++side) {
+      const uint32_t *b = w + side * WC;
+      for (int r = 0; r < N; ++r)
+        for (int c = 0; c < N; ++c)
+          for (int d = 0; d < 4; ++d) {
+            int k = 0;
+            for (; k < 5; ++k) {
+              const int rr = r + k * DR[d], cc = c + k * DC[d];
+              if (rr < 0 || rr >= N || cc < 0 || cc >= N) break;
+              const int i = rr * N + cc;
+              if (!((b[i >> 5] >> (i & 31)) & 1u)) break;
+            }
+            if (k == 5) return true;
+          }
+    }
+    return false;
   }
 };
 

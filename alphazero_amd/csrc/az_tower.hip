@@ -616,7 +616,11 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) voi
     }
     STAMP(3);
     lookup();  // the ticket drawn at the top of the loop has long arrived
-    if (L == 0) fetch(inb);
+    if (L == 0) {  // no conv layer (and so no stage barrier) follows: the next group's ticket, slots and input must have
+      fetch(inb);  // landed before any wave reads them at the loop top
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
       {  // res = this block's input
@@ -809,16 +813,72 @@ __global__ __launch_bounds__(256, 2) void k_heads(const uint16_t *__restrict__ f
 
 }  // namespace aztower
 
-static std::string g_tower_err;
+static thread_local std::string g_tower_err;  // per host thread: engines on different threads do not share (or race on) a message
 
 // Ticket counters of the tower launches: {next group, workgroups done} pairs, zero at load and re-armed by each launch's
-// last workgroup.  Launches rotate through 16 pairs, so up to 16 launches may be in flight on one GPU (e.g. two
-// engines on two streams).  A __device__ array exists once per GPU; its address is looked up per device.
-#define AZ_TOWER_TICKET_PAIRS 16
+// last workgroup, so a pair is free again as soon as its launch has ended.  Two launches may share a pair only if they
+// cannot overlap, hence:
+//   - eager launches: one pair per (GPU, stream) -- launches on one stream run in order; pairs 0 .. EAGER-1, looked up in
+//     a small table (least recently used entry recycled when more than EAGER streams have launched towers on the GPU);
+//   - launches recorded into a HIP graph (stream capture): each gets a pair of its own from EAGER .. PAIRS-1, round
+//     robin, never handed to an eager stream -- a graph replays with the pair baked in, on whatever stream replays it.
+//     (More than PAIRS - EAGER captured tower launches alive at once may share pairs: replay those graphs on one stream.)
+// A __device__ array exists once per GPU; its address is looked up per device, for the device that owns the stream.
+#define AZ_TOWER_TICKET_PAIRS 64
+#define AZ_TOWER_EAGER_PAIRS 32
 static __device__ unsigned int g_tower_tickets[2 * AZ_TOWER_TICKET_PAIRS];
 static std::mutex g_ticket_mutex;  // engines on different host threads may launch towers on the same GPU
-static unsigned int *g_ticket_base[64];
-static unsigned int g_ticket_seq[64];
+struct TicketDev {
+  unsigned int *base;
+  hipStream_t stream[AZ_TOWER_EAGER_PAIRS];
+  unsigned long long used[AZ_TOWER_EAGER_PAIRS];
+  int n_streams;
+  unsigned long long clock;
+  unsigned int cap_seq;
+  unsigned int attr_done;  // bit k: hipFuncSetAttribute issued for kernel variant k on this GPU
+};
+static TicketDev g_td[64];
+
+// the device a launch on `stream` runs on (the current device for the NULL stream)
+static int tower_device(hipStream_t stream, int *dev) {
+  hipDevice_t d = 0;
+  if (stream != nullptr && hipStreamGetDevice(stream, &d) == hipSuccess) { *dev = (int)d; return 0; }
+  (void)hipGetLastError();
+  return hipGetDevice(dev) == hipSuccess ? 0 : -1;
+}
+
+// -> the ticket pair of this launch, or nullptr (message in g_tower_err).  `dev` is current.
+static unsigned int *tower_tickets(int dev, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_ticket_mutex);
+  TicketDev &t = g_td[dev];
+  if (t.base == nullptr) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tower_tickets)) != hipSuccess || p == nullptr) {
+      g_tower_err = "hipGetSymbolAddress(g_tower_tickets) failed";
+      return nullptr;
+    }
+    t.base = (unsigned int *)p;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (stream != nullptr && hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+  if (cs == hipStreamCaptureStatusActive)
+    return t.base + 2 * (AZ_TOWER_EAGER_PAIRS + (t.cap_seq++ % (AZ_TOWER_TICKET_PAIRS - AZ_TOWER_EAGER_PAIRS)));
+  ++t.clock;
+  int slot = -1;
+  for (int i = 0; i < t.n_streams; ++i)
+    if (t.stream[i] == stream) { slot = i; break; }
+  if (slot < 0) {
+    if (t.n_streams < AZ_TOWER_EAGER_PAIRS) slot = t.n_streams++;
+    else {  // recycle the least recently used entry (a stream that has long been idle or destroyed)
+      slot = 0;
+      for (int i = 1; i < AZ_TOWER_EAGER_PAIRS; ++i)
+        if (t.used[i] < t.used[slot]) slot = i;
+    }
+    t.stream[slot] = stream;
+  }
+  t.used[slot] = t.clock;
+  return t.base + 2 * slot;
+}
 
 extern "C" {
 
@@ -862,24 +922,30 @@ int az_tower_forward(int32_t board_size, int32_t channels, int32_t n_boards, int
   if (feat_stride < az_heads_feat_stride(board_size)) { g_tower_err = "feat_stride below az_heads_feat_stride(board_size)"; return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   hipError_t err;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { g_tower_err = "hipGetDevice failed"; return AZ_EHIP; }
-  unsigned int *tickets = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(g_ticket_mutex);
-    if (g_ticket_base[dev] == nullptr) {
-      void *p = nullptr;
-      if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tower_tickets)) != hipSuccess || p == nullptr) {
-        g_tower_err = "hipGetSymbolAddress(g_tower_tickets) failed";
-        return AZ_EHIP;
-      }
-      g_ticket_base[dev] = (unsigned int *)p;
-    }
-    tickets = g_ticket_base[dev] + 2 * (g_ticket_seq[dev]++ % AZ_TOWER_TICKET_PAIRS);
-  }
+  int dev = 0, cur = 0;
+  if (tower_device(s, &dev) != 0 || dev < 0 || dev >= 64) { g_tower_err = "cannot tell the stream's device"; return AZ_EHIP; }
+  if (hipGetDevice(&cur) != hipSuccess) { g_tower_err = "hipGetDevice failed"; return AZ_EHIP; }
+  // the counters and the launch belong to the stream's GPU, whatever device the calling thread has current
+  struct DeviceGuard {
+    int back;
+    DeviceGuard(int want, int cur_) : back(want != cur_ ? cur_ : -1) { if (back >= 0) (void)hipSetDevice(want); }
+    ~DeviceGuard() { if (back >= 0) (void)hipSetDevice(back); }
+  } guard(dev, cur);
+  unsigned int *tickets = tower_tickets(dev, s);
+  if (tickets == nullptr) return AZ_EHIP;
+  int variant = 0;
   auto launch = [&](auto kern, size_t lds, int bpw, int nw, int wg_per_cu) -> int {
     if (lds * wg_per_cu > 160 * 1024) { g_tower_err = "tower geometry exceeds the CU's LDS"; return AZ_EINVAL; }
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {  // once per kernel variant and GPU
+      std::lock_guard<std::mutex> lock(g_ticket_mutex);
+      if (!(g_td[dev].attr_done & (1u << variant))) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          g_tower_err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+          return AZ_EHIP;
+        }
+        g_td[dev].attr_done |= 1u << variant;
+      }
+    }
     const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * wg_per_cu;  // workgroups that fit the chip
     const int grid = groups < cap ? groups : cap;
     const bool use_list = !x_bf16_dev && list_dev && count_dev;
@@ -896,11 +962,13 @@ int az_tower_forward(int32_t board_size, int32_t channels, int32_t n_boards, int
   if (channels == 64) {
     using G15 = Geo<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, 64>;
     using G9 = Geo<9, 3, 2, AZ_TOWER9_ST, 64>;
+    variant = board_size == 15 ? 0 : 1;
     if (board_size == 15) rc = launch(k_tower<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, 64>, G15::lds_bytes(), AZ_TOWER15_BPW, G15::NW, AZ_TOWER_WAVES_PER_SIMD);
     else rc = launch(k_tower<9, 3, 2, AZ_TOWER9_ST, 64>, G9::lds_bytes(), 3, G9::NW, AZ_TOWER_WAVES_PER_SIMD);
   } else {
     using G15 = Geo<15, 1, 2, 1, 128>;
     using G9 = Geo<9, 3, 2, 1, 128>;
+    variant = board_size == 15 ? 2 : 3;
     if (board_size == 15) rc = launch(k_tower<15, 1, 2, 1, 128>, G15::lds_bytes(), 1, G15::NW, 1);
     else rc = launch(k_tower<9, 3, 2, 1, 128>, G9::lds_bytes(), 3, G9::NW, 1);
   }

@@ -137,6 +137,10 @@ class FusedTowerEvaluator:
         if logits.dtype != torch.float32 or not logits.is_contiguous() or tuple(logits.shape) != (B, self.n2):
             raise EngineError("FusedTowerEvaluator: logits_out must be a contiguous (B, N*N) float32 tensor")
         P = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            return self._launch(x, P, B, ring_p, leaf_p, list_p, count_p, flags_p, feat, logits, value)
+
+    def _launch(self, x, P, B, ring_p, leaf_p, list_p, count_p, flags_p, feat, logits, value):
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if self.kernel_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

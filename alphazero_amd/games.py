@@ -8,7 +8,7 @@ have native rule kernels.  Same static interface on CPU float32 tensors --
 -- and the same instance surface (reset / step / get_state / get_player / get_history / get_legal_mask
 / evaluation), so code written against the reference's ``BaseGame`` (UI, evaluation scripts, the
 ``MCTS.search`` adapter's callers) runs against these classes on a machine where the reference is
-absent.  The GPU engine never calls them: rules run as bitboard kernels (csrc/az_games.cuh); these
+absent.  The GPU engine never calls them: rules run as bitboard kernels (csrc/az_games.hip.h); these
 exist for positions entering and leaving the engine and for tests.  PLAYER1 = 1, PLAYER2 = -1
 (config/basic.py:3-4); rule violations raise ValueError like the reference.
 """

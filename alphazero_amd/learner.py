@@ -40,11 +40,14 @@ class DataParallelLearner:
     The reference has no counterpart: its learner is one process (training/nn_trainer.py:36-94)."""
 
     def __init__(self, model: torch.nn.Module, optim: torch.optim.Optimizer, bucket_bytes: int = 32 << 20,
-                 process_group=None):
+                 process_group=None, force_collectives: bool = False):
+        """force_collectives: run the hook / all-reduce path even with one rank (a process group must be initialised):
+        how a one-GPU box exercises the code every rank of an N-GPU job runs."""
         import torch.distributed as dist
 
         self.model, self.optim, self.group = model, optim, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (force_collectives and dist.is_initialized())
         params = [p for p in model.parameters() if p.requires_grad]
         self.buckets: list[torch.Tensor] = []
         self._bucket_of: dict[int, int] = {}
@@ -74,17 +77,24 @@ class DataParallelLearner:
         close()
         self._left = list(self._need)
         self._handles: list = []
-        if self.world > 1:
+        self._sent: list[bool] = [False] * len(self.buckets)
+        self.collectives_issued = 0
+        if self.collective:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
-    def _on_grad(self, p: torch.nn.Parameter) -> None:
+    def _send(self, b: int) -> None:
         import torch.distributed as dist
 
+        self._sent[b] = True
+        self.collectives_issued += 1
+        self._handles.append(dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
         b = self._bucket_of[id(p)]
         self._left[b] -= 1
         if self._left[b] == 0:
-            self._handles.append(dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._send(b)
 
     def step(self, pool, batch_size: int = 64):
         """one data-parallel Trainer.train(): every rank samples its own batch_size rows from its own pool"""
@@ -98,13 +108,21 @@ class DataParallelLearner:
             flat.zero_()
         self._left = list(self._need)
         self._handles = []
+        self._sent = [False] * len(self.buckets)
         loss, pl, vl = calculate_loss(self.model, states, pis, zs)
         loss.backward()
-        for h in self._handles:
-            h.wait()
-        if self.world > 1:
-            for flat in self.buckets:
-                flat.div_(self.world)
+        if self.collective:
+            # A bucket whose hooks did not all fire (a parameter that took no part in this step's graph: its gradient
+            # stays zero) is reduced here, in bucket order, so that every rank issues every bucket exactly once per
+            # step.  (As with any data-parallel scheme the SET of unused parameters must be the same on every rank.)
+            for b in range(len(self.buckets)):
+                if not self._sent[b]:
+                    self._send(b)
+            for h in self._handles:
+                h.wait()
+            if self.world > 1:
+                for flat in self.buckets:
+                    flat.div_(self.world)
         self.optim.step()
         self.model.eval()
         return float(loss.detach()), float(pl), float(vl)

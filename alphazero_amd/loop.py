@@ -29,21 +29,28 @@ class SelfPlayTrainLoop:
                  device: torch.device, *, ring_capacity: int = 1 << 18, batch_size: int = 512,
                  train_steps_per_move: int = 1, min_samples: int = 4096, lr: float = 1e-3,
                  nn_dtype: torch.dtype = torch.bfloat16, fused: Optional[bool] = None,
-                 publish_every: int = UPDATE_MODEL_FREQUENCY):
+                 publish_every: int = UPDATE_MODEL_FREQUENCY, force_collectives: bool = False,
+                 engine=None, runner=None, ring=None):
+        """engine / runner / ring: prebuilt parts (the CPU tests of the multi-rank control flow hand in stand-ins that
+        need no GPU); by default they are built here from the other arguments."""
         self.device = device
+        self.force_collectives = force_collectives
         self.master = model.to(device).float()  # the learner's f32 weights
         self.optim = torch.optim.Adam(self.master.parameters(), lr=lr)
-        self.learner = DataParallelLearner(self.master, self.optim)
+        self.learner = DataParallelLearner(self.master, self.optim, force_collectives=force_collectives)
         self.publisher = WeightPublisher(self.master, src=0)
-        self.publisher.publish()  # every rank starts from rank 0's weights
+        self.publisher.publish(force=force_collectives)  # every rank starts from rank 0's weights
         self.player = copy.deepcopy(self.master).to(nn_dtype).eval()  # the self-play copy (bf16 by default)
-        self.engine = Engine(game, n_slots, num_sims, board_size=board_size, nn_dtype=nn_dtype, device=device)
-        if fused is None:
-            from .fused import FusedTowerEvaluator
+        self.engine = engine if engine is not None else \
+            Engine(game, n_slots, num_sims, board_size=board_size, nn_dtype=nn_dtype, device=device)
+        if runner is None:
+            if fused is None:
+                from .fused import FusedTowerEvaluator
 
-            fused = nn_dtype == torch.bfloat16 and FusedTowerEvaluator.supports(self.player)
-        self.runner = SelfPlayRunner(self.engine, self.player, num_sims, fused=bool(fused))
-        self.ring = DeviceSampleRing(self.engine, ring_capacity)
+                fused = nn_dtype == torch.bfloat16 and FusedTowerEvaluator.supports(self.player)
+            runner = SelfPlayRunner(self.engine, self.player, num_sims, fused=bool(fused))
+        self.runner = runner
+        self.ring = ring if ring is not None else DeviceSampleRing(self.engine, ring_capacity)
         self.batch_size, self.train_steps_per_move = batch_size, train_steps_per_move
         self.min_samples, self.publish_every = min_samples, publish_every
         self.n_slots = n_slots
@@ -59,8 +66,23 @@ class SelfPlayTrainLoop:
         dst = self.player.state_dict()
         for k, v in self.master.state_dict().items():
             dst[k].copy_(v)
-        if self.runner.fused is not None:
+        if getattr(self.runner, "fused", None) is not None:
             self.runner.fused.refresh()
+
+    def _all_ranks_ready(self) -> bool:
+        """Training is a collective (gradient all-reduce, weight broadcast), so the decision to train this move must be
+        one too: every rank trains exactly when EVERY rank's ring holds min_samples.  Ranks play different games and
+        cross the threshold on different moves; a rank-local test would leave the early ranks blocked in an all-reduce
+        their peers never post.  One 4-byte MIN all-reduce per move (a move is hundreds of ms of search)."""
+        import torch.distributed as dist
+
+        ready = self.ring.size() >= self.min_samples
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collectives):
+            dev = self.device if torch.device(self.device).type == "cuda" else torch.device("cpu")
+            flag = torch.tensor([1 if ready else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ready = bool(int(flag.item()))
+        return ready
 
     def move(self) -> None:
         """one self-play move of every game, then the learner's share of work"""
@@ -80,13 +102,13 @@ class SelfPlayTrainLoop:
             self.inv_tao.copy_(self.inv_tao_h, non_blocking=True)
             eng.reset_games(done)
         self.moves += 1
-        if self.ring.size() >= self.min_samples:
+        if self._all_ranks_ready():  # the same answer on every rank => the same number of collectives below
             for _ in range(self.train_steps_per_move):
                 self.last_loss = self.learner.step(self.ring, self.batch_size)
                 self.loss_history.append(self.last_loss[0])
-                self.train_steps += 1
+                self.train_steps += 1  # identical on every rank (see _all_ranks_ready), so is the publish schedule
                 if self.publish_every and self.train_steps % self.publish_every == 0:
-                    self.publisher.publish()
+                    self.publisher.publish(force=self.force_collectives)
             self._refresh_player()
 
     def run(self, n_moves: int) -> dict:

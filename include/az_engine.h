@@ -91,7 +91,11 @@ int az_reset_games(az_engine *e, const uint8_t *mask_dev, void *stream);
 /* Load an arbitrary position into one slot (the MCTS.search(root_state, root_player,
  * history_state) arguments, core/MCTS_alphazero.py:128-137).  history_host: 8 states of
  * state_channels*height*width f32 each, oldest first, newest == root state (utils/history_manager.py:41-47).
- * Host pointer; synchronous. */
+ * Host pointer; synchronous.  A root that is already decided (a side has won, or no move is left) is refused with
+ * AZ_EINVAL: the reference evaluates such a node by rule (:157-158), there is nothing to search.  The slot gets a
+ * fresh root (no tree, zero root statistics); it may be searched and played on, but it has no trajectory before the
+ * root, so az_emit_samples refuses it (device error flag, AZ_EDEVICE from az_check) unless the root is the initial
+ * position. */
 int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32_t root_player, void *stream);
 
 /* core/MCTS_alphazero.py:142  a fresh, unexpanded root for every active slot (no tree reuse). */
@@ -209,7 +213,10 @@ int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *log
  *   [policy N*N | zero pad to a multiple of 16 | value0 N*N | value1 N*N | zero pad to a multiple of 16];
  *   feat_stride >= az_heads_feat_stride(N) elements; the pads are never written: hand in a zeroed buffer.
  *   board_size N in {9, 15}.  Groups of boards are handed to workgroups through a ticket counter that lives in the
- *   library (16 pairs per GPU, rotated per launch): at most 16 launches may be in flight on one GPU. */
+ *   library, on the GPU that owns `stream` (the calling thread's current device is irrelevant): one counter pair per
+ *   stream for eager launches (32 streams per GPU before the least recently used entry is recycled), a pair of its
+ *   own for every launch recorded into a HIP graph (32 per GPU before they repeat).  Errors: az_tower_last_error(),
+ *   per host thread. */
 int az_tower_forward(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const void *x_bf16_dev,
                      const void *packed_ring_dev, const void *packed_leaf_dev, const void *list_dev,
                      const void *count_dev, const void *flags_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev,

@@ -9,7 +9,7 @@ from alphazero_amd.nets import GomokuNet
 torch.manual_seed(0)
 dev = torch.device("cuda", 0)
 sims = int(os.environ.get("SIMS", "200"))
-model = GomokuNet(15, 64, 2).eval().to(dev).to(torch.bfloat16)
+model = None  # built in __main__ (nothing touches the GPU at import)
 
 
 def make(slots, graph):
@@ -56,5 +56,7 @@ def bench(parts, graph, moves=3):
     del ers
 
 
-for parts, graph in ((1, False), (2, False), (2, True)):
-    bench(parts, graph)
+if __name__ == "__main__":
+    model = GomokuNet(15, 64, 2).eval().to(dev).to(torch.bfloat16)
+    for parts, graph in ((1, False), (2, False), (2, True)):
+        bench(parts, graph)

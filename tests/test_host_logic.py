@@ -188,3 +188,135 @@ def test_data_parallel_learner_world_size_2_gloo(tmp_path):
     script.write_text(_DP_WORKER)
     procs = [subprocess.Popen([sys.executable, str(script), str(r), str(port), ROOT]) for r in range(2)]
     assert [p.wait(timeout=180) for p in procs] == [0, 0]
+
+
+_LOOP_WORKER = r"""
+import sys, torch, torch.distributed as dist
+rank, port, root = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+sys.path.insert(0, root)
+from alphazero_amd.loop import SelfPlayTrainLoop
+from alphazero_amd.nets import TicTacToeNet
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+torch.manual_seed(rank)  # different initial weights per rank: the first publish must make them equal
+G = 8
+
+
+class StubEngine:  # stands in for the HIP engine: rank 0's games end every move, rank 1's every fourth move
+    def __init__(self):
+        self.moves = 0
+    def game_info(self):
+        return torch.full((G,), 5, dtype=torch.int32), None, None, None
+    def emit_samples(self, slots, plies):
+        n = int(torch.as_tensor(plies).sum())
+        g = torch.Generator().manual_seed(100 * rank + self.moves)
+        return (torch.randint(-1, 2, (n, 81), generator=g).float(), torch.softmax(torch.randn(n, 9, generator=g), 1),
+                torch.randint(-1, 2, (n,), generator=g).float(), None)
+    def reset_games(self, mask):
+        pass
+    def check(self):
+        pass
+
+
+class StubRunner:
+    fused = None
+    def __init__(self, eng):
+        self.e = eng
+    def move_round(self, inv_tao):
+        self.e.moves += 1
+        done = torch.zeros(G, dtype=torch.uint8)
+        if rank == 0 or self.e.moves % 4 == 0:
+            done[: 2 + rank] = 1
+        return None, done
+
+
+class StubRing:
+    def __init__(self):
+        self.s, self.p, self.z = [], [], []
+    def put_games(self, s, p, z):
+        self.s.append(s); self.p.append(p); self.z.append(z)
+    def size(self):
+        return sum(t.shape[0] for t in self.s)
+    def sample(self, n, timeout=None):
+        s, p, z = torch.cat(self.s), torch.cat(self.p), torch.cat(self.z)
+        i = torch.randint(0, s.shape[0], (n,))
+        return s[i].view(-1, 9, 3, 3), p[i], z[i].view(-1, 1)
+
+
+eng = StubEngine()
+loop = SelfPlayTrainLoop(TicTacToeNet(), 0, 3, G, 4, torch.device("cpu"), batch_size=16, train_steps_per_move=2, min_samples=40,
+                         nn_dtype=torch.float32, publish_every=3, engine=eng, runner=StubRunner(eng), ring=StubRing())
+trained_at = []
+for m in range(14):
+    before = loop.train_steps
+    loop.move()
+    if loop.train_steps != before:
+        trained_at.append(m)
+# rank 0 alone reaches 40 samples after 4 moves (10 per move); rank 1 gets 15 every fourth move => 45 after move 12:
+# nobody may train before that, and both must have run the same number of steps (= the same number of collectives)
+steps = torch.tensor([loop.train_steps, trained_at[0] if trained_at else -1])
+both = [torch.empty_like(steps) for _ in range(2)]
+dist.all_gather(both, steps)
+ok = torch.equal(both[0], both[1]) and loop.train_steps == 2 * len(trained_at) and trained_at and trained_at[0] == 11
+loop.publisher.publish()
+flat = torch.cat([q.detach().reshape(-1) for q in loop.master.parameters()])
+other = [torch.empty_like(flat) for _ in range(2)]
+dist.all_gather(other, flat)
+ok = ok and torch.equal(other[0], other[1])
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+"""
+
+
+def test_train_loop_control_flow_world_size_2_gloo(tmp_path):
+    """SelfPlayTrainLoop.move() with ranks whose rings fill at different rates: the decision to train is collective, so
+    nobody trains before every rank is ready, nobody hangs, and the weights agree after a publish."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "loop.py"
+    script.write_text(_LOOP_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(port), ROOT]) for r in range(2)]
+    assert [p.wait(timeout=180) for p in procs] == [0, 0]
+
+
+def test_learner_reduces_buckets_whose_hooks_did_not_fire(tmp_path):
+    """A frozen-in-place (unused) parameter: its bucket is still all-reduced once per step, and the hook path runs with
+    one rank under force_collectives (what a one-GPU box can exercise)."""
+    import torch
+    import torch.distributed as dist
+
+    from alphazero_amd.learner import DataParallelLearner
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.body = torch.nn.Linear(9 * 9, 9)
+                self.unused = torch.nn.Linear(4, 4)  # never takes part in forward
+                self.v = torch.nn.Linear(9 * 9, 1)
+
+            def forward(self, x):
+                x = x.reshape(x.shape[0], -1)
+                return self.body(x), torch.tanh(self.v(x))
+
+        torch.manual_seed(0)
+        net = Net()
+        dp = DataParallelLearner(net, torch.optim.SGD(net.parameters(), lr=0.1), bucket_bytes=64, force_collectives=True)
+        assert dp.collective and len(dp.buckets) >= 3
+        batch = (torch.randn(8, 9, 3, 3), torch.softmax(torch.randn(8, 9), 1), torch.randn(8, 1))
+
+        class Pool:
+            def sample(self, n, timeout=None):
+                return batch
+
+        w_unused = net.unused.weight.detach().clone()
+        for k in range(2):
+            dp.step(Pool(), 8)
+            assert dp.collectives_issued == (k + 1) * len(dp.buckets)  # every bucket exactly once per step
+        assert torch.equal(net.unused.weight, w_unused)  # zero gradient, untouched
+    finally:
+        dist.destroy_process_group()
