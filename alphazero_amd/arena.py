@@ -220,11 +220,15 @@ class ChessArena:
 
     # ---- batched extension --------------------------------------------------------------------
     def self_play_many(self, n_games: int, tao: TaoSchedule, experience_pool, *, slots: Optional[int] = None,
-                       reference_rng: bool = False) -> dict:
+                       reference_rng: bool = False, trace: Optional[list] = None) -> dict:
         """Play n_games games, up to ``slots`` at a time; every finished game's samples go to
         ``experience_pool.put_tupule_experience`` exactly as training/self_play.py:110-139 puts them
         ((1,C_in,H,W) f32, (1,A) f32, (1,) f32 CPU tensors, last position first).  Pools that offer
-        ``put_batch(states, pis, zs)`` get whole games' samples in one call instead."""
+        ``put_batch(states, pis, zs)`` get whole games' samples in one call instead.
+
+        ``trace``: a list that receives one dict per move round -- the Dirichlet and Exponential rows the device drew
+        for every slot, 1/tao, the actions played, the slots whose game ended (in the order their samples were put)
+        and the slots restarted -- enough to replay every game elsewhere (the parity tests do, on the CPU oracle)."""
         slots = min(slots or self.n_slots, n_games)
         eng = self._engine(slots)
         run = SelfPlayRunner(eng, self.model, self.num_simulation, alpha=self.alpha, reference_rng=reference_rng)
@@ -245,9 +249,12 @@ class ChessArena:
         finished = samples = 0
         put_batch = getattr(experience_pool, "put_batch", None)
         while finished < n_games:
-            _, done = run.move_round(inv_tao)
+            acts, done = run.move_round(inv_tao)
             done_h = done.cpu()
             idx = torch.nonzero(done_h).reshape(-1)
+            if trace is not None:
+                trace.append({"noise": run.noise.cpu().clone(), "expo": run.expo.cpu().clone(), "inv_tao": inv_tao.cpu().clone(),
+                              "actions": acts.cpu().clone(), "finished": idx.tolist(), "restarted": []})
             if idx.numel() == 0:
                 continue
             plies, _, _, _ = eng.game_info()
@@ -270,6 +277,8 @@ class ChessArena:
                     restart[s] = 1
                     inv_tao_h[s] = 1.0 / tao_of(self.games_played + started)
                     started += 1
+            if trace is not None:
+                trace[-1]["restarted"] = torch.nonzero(restart).reshape(-1).tolist()
             if bool(restart.any()):
                 inv_tao.copy_(inv_tao_h)
                 eng.reset_games(restart.to(eng.device))

@@ -780,6 +780,36 @@ __global__ __launch_bounds__(64) void k_eval_hash(int nin, int A, const InT *nn_
   }
 }
 
+// The same evaluator fed from the PACKED leaf batch (8 bitboard states + the player of the leaf record): what a caller
+// that passes nn_input == NULL to az_select_gather / az_expand_select has to read -- same numbers as k_eval_hash on the
+// dense planes of the same leaves (the hash is a commutative sum over the input elements).
+template <class GT>
+__global__ __launch_bounds__(64) void k_eval_hash_packed(View v, float scale, float *logits, float *values) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if (!v.evalFlag[g]) return;  // terminal leaf / inactive slot: the row keeps its old contents, as with the dense batch
+  constexpr int NIN = GT::CIN * GT::HW, A = GT::A;
+  __shared__ uint32_t ring[8][GT::SW];
+  for (int i = lane; i < 8 * GT::SW; i += 64) ring[i / GT::SW][i % GT::SW] = v.leafRing[(size_t)g * 8 * GT::SW + i];
+  const int player = v.leaf[g].w;
+  __syncthreads();
+  uint32_t h = 0;
+  for (int i = lane; i < NIN; i += 64) {
+    const int c = i / GT::HW, cell = i % GT::HW;
+    const float x = c == GT::CIN - 1 ? (float)player : GT::plane(ring[c / GT::CS], c % GT::CS, cell);
+    const uint32_t code = (uint32_t)((int)x + 1);
+    h += mix32((uint32_t)i * 2654435761u + code * 40503u + 12345u);
+  }
+  h = (uint32_t)wave_sum_i((int)h);
+  for (int a = lane; a < A; a += 64) {
+    const uint32_t r = mix32(h + (uint32_t)a * 0x9E3779B9u + 1u);
+    logits[(size_t)g * A + a] = scale * ((float)((r >> 8) & 0xFFFFu) * (1.0f / 65536.0f) - 0.5f);
+  }
+  if (lane == 0) {
+    const uint32_t r = mix32(h ^ 0x00ABCDEFu);
+    values[g] = (float)((r >> 8) & 0xFFFFu) * (1.0f / 32768.0f) - 1.0f;
+  }
+}
+
 }  // namespace az
 
 // =========================================================================== host side =========
@@ -1225,11 +1255,15 @@ int az_reset_stats(az_engine *e, void *stream) {
 }
 
 int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *logits_dev, float *values_dev, void *stream) {
-  if (!e || !nn_input_dev || !logits_dev || !values_dev) return AZ_EINVAL;
+  if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
   DeviceGuard guard(e->cfg.device);
   const dim3 grid(e->v.G), block(64);
   hipStream_t s = (hipStream_t)stream;
   const int A = e->dims.n_action;
+  if (!nn_input_dev) {  // read the packed leaf batch of the last descent
+    AZ_DISPATCH(e, hipLaunchKernelGGL((k_eval_hash_packed<GT>), grid, block, 0, s, e->v, scale, logits_dev, values_dev));
+    return launch_check(e, "k_eval_hash_packed");
+  }
   switch (e->cfg.nn_dtype) {
     case AZ_NN_F32: hipLaunchKernelGGL((k_eval_hash<float>), grid, block, 0, s, e->nin, A, (const float *)nn_input_dev, scale, logits_dev, values_dev); break;
     case AZ_NN_BF16: hipLaunchKernelGGL((k_eval_hash<bf16_t>), grid, block, 0, s, e->nin, A, (const bf16_t *)nn_input_dev, scale, logits_dev, values_dev); break;

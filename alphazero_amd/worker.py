@@ -27,7 +27,7 @@ def sync_model_from_shared(model: torch.nn.Module, model_state: dict, lock: Any)
 
 def gpu_self_player_worker(model_cls, game_cls, model_state, experience_pool, num_self_play_games: int, worker_id: int,
                            model_lock: Any, *, seed_bias: int = 0, n_slots: int = 1024, num_simulation: int = 80,
-                           device: torch.device | None = None) -> None:
+                           device: torch.device | None = None, trace: list | None = None) -> None:
     try:
         seed = seed_bias + worker_id
         random.seed(seed)
@@ -42,7 +42,7 @@ def gpu_self_player_worker(model_cls, game_cls, model_state, experience_pool, nu
         played = 0
         while played < num_self_play_games:
             n = min(chunk, num_self_play_games - played)
-            arena.self_play_many(n, lambda i: reference_tao(i // max(n_slots, 1)), experience_pool)
+            arena.self_play_many(n, lambda i: reference_tao(i // max(n_slots, 1)), experience_pool, trace=trace)
             played += n
             if played < num_self_play_games:
                 sync_model_from_shared(arena.model, model_state, model_lock)

@@ -193,7 +193,8 @@ int az_reset_stats(az_engine *e, void *stream);
 
 /* No counterpart in the reference: a deterministic synthetic evaluator ("hash network") with exact
  * f32 outputs, so tree parity can be tested bit for bit without a neural network and the tree
- * kernels can be benchmarked alone.  Reads the batch written by az_select_gather. */
+ * kernels can be benchmarked alone.  Reads the batch written by az_select_gather; nn_input_dev == NULL: reads the packed
+ * leaf batch instead (same outputs; rows of slots whose leaf needs no evaluation are left untouched). */
 int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *logits_dev,
                  float *values_dev, void *stream);
 

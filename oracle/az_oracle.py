@@ -143,7 +143,7 @@ def self_play(game, board_size, num_sim, tao, expo, eval_fn, ctx=None, noise=Non
     stats = np.zeros(4, np.float64)
     rc = lib().az_oracle_self_play(
         C.c_int(game), C.c_int(board_size), C.c_int(num_sim), C.c_float(c_puct), C.c_float(epsilon),
-        C.c_float(tao), _p(noise, _f32p), _p(expo, _f32p), C.c_int(max_plies), eval_fn, ctx,
+        C.c_double(tao), _p(noise, _f32p), _p(expo, _f32p), C.c_int(max_plies), eval_fn, ctx,
         _p(actions, _i32p), _p(players, _i32p), _p(states, _f32p), _p(pis, _f32p), _p(z, _f32p),
         C.byref(result), _p(stats, _f64p))
     if rc <= 0:

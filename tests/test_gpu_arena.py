@@ -210,3 +210,88 @@ def test_copy_to_host_moves_every_byte():
         assert torch.equal(dst, src.cpu())
     with pytest.raises(EngineError):
         copy_to_host(torch.zeros(4), torch.zeros(4, device="cuda"))  # not pinned
+
+
+def _replay_trace(oracle, trace, pool_items, game, n, A, sims, slots, tao_of_game, max_plies):
+    """Rebuild every game of a traced self_play_many run (per-slot draws of every move round, recycling included) and
+    replay it on the CPU oracle: actions, the samples the pool received (put order: finished games in slot order per
+    round, last position first) and z must agree bit for bit.  training/self_play.py:30-139."""
+    d = oracle.dims(game, n)
+    ev = oracle.torch_eval(HashNet(A, 5.0), (d["cin"], d["H"], d["W"]))
+    cur = {s: {"noise": [], "expo": [], "actions": [], "game": s} for s in range(slots)}
+    next_game = slots
+    k = 0  # cursor into pool_items
+    games_checked = 0
+    for rnd in trace:
+        for s, g in cur.items():
+            if g is None:
+                continue
+            a = int(rnd["actions"][s])
+            if a < 0:
+                continue
+            g["noise"].append(rnd["noise"][s].numpy())
+            g["expo"].append(rnd["expo"][s].numpy())
+            g["actions"].append(a)
+            g["inv_tao"] = float(rnd["inv_tao"][s])
+        for s in rnd["finished"]:
+            g = cur[s]
+            T = len(g["actions"])
+            tao = tao_of_game(g["game"])
+            assert np.float32(1.0 / tao) == np.float32(g["inv_tao"])
+            expo = np.zeros((max_plies, A), np.float32)
+            noise = np.zeros((max_plies, A), np.float32)
+            expo[:T], noise[:T] = np.stack(g["expo"]), np.stack(g["noise"])
+            expo[T:] = 1.0
+            r = oracle.self_play(game, n, sims, tao, expo, ev, noise=noise, max_plies=max_plies)
+            assert r["plies"] == T and list(r["actions"]) == g["actions"], (s, g["game"])
+            for j in range(T):  # put order: last position first
+                st, pi, z = pool_items[k + j]
+                t = T - 1 - j
+                assert np.array_equal(st.numpy().reshape(-1), r["nn_states"][t])
+                assert np.array_equal(pi.numpy().reshape(-1), r["pis"][t])
+                assert float(z.reshape(-1)[0]) == float(r["z"][t])
+            k += T
+            games_checked += 1
+            cur[s] = None
+        for s in rnd["restarted"]:
+            cur[s] = {"noise": [], "expo": [], "actions": [], "game": next_game}
+            next_game += 1
+    assert k == len(pool_items)
+    return games_checked
+
+
+@pytest.mark.parametrize("name,game,n,A,sims", GAMES)
+def test_self_play_many_with_recycling_replays_on_the_oracle(oracle, name, game, n, A, sims):
+    """multi-slot self-play with slot recycling (device-drawn Dirichlet / exponential rows captured per move round)
+    == oracle.self_play game by game: actions, samples, z"""
+    from alphazero_amd.arena import ChessArena
+
+    slots, n_games = 6, 15
+    max_plies = {0: 9, 1: 24, 2: 81}[game]
+    torch.manual_seed(11)
+    arena = ChessArena(functools.partial(HashNet, A, 5.0), _game_cls(name), torch.device("cuda:0"), n_slots=slots,
+                       num_simulation=sims)
+    pool, trace = ListPool(), []
+    taos = [1.0, 0.8, 0.5]
+    tao_of = lambda i: taos[i % 3]
+    arena.self_play_many(n_games, tao_of, pool, trace=trace)
+    assert _replay_trace(oracle, trace, pool.items, game, n, A, sims, slots, tao_of, max_plies) == n_games
+
+
+def test_gpu_worker_replays_on_the_oracle(oracle):
+    """f-1: the same comparison through gpu_self_player_worker (the reference worker's signature and temperature
+    schedule, training/alphazero_trainer.py:164-221)"""
+    import threading
+
+    from alphazero_amd.arena import reference_tao
+    from alphazero_amd.games import DotsAndBoxesGame
+    from alphazero_amd.worker import gpu_self_player_worker
+
+    A, sims, slots, n_games = 24, 16, 4, 9
+    model_cls = functools.partial(HashNet, A, 5.0)
+    shared = {k: v.clone() for k, v in model_cls().state_dict().items()}
+    pool, trace = ListPool(), []
+    gpu_self_player_worker(model_cls, DotsAndBoxesGame, shared, pool, n_games, 0, threading.Lock(), n_slots=slots,
+                           num_simulation=sims, trace=trace)
+    tao_of = lambda i: reference_tao(i // slots)
+    assert _replay_trace(oracle, trace, pool.items, 1, 3, A, sims, slots, tao_of, 24) == n_games

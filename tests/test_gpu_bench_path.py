@@ -1,0 +1,157 @@
+"""Parity of the path bench.py actually times (BASELINE configs[3]): ``SelfPlayRunner.search()`` on gomoku 15x15 =
+az_begin_search, az_select_gather(nn_input = NULL), then (evaluate, az_expand_select(nn_input = NULL)) per simulation --
+the k_expand_select<Gomoku<15>, bf16> instantiation with the register hand-over between backup and next descent, the
+packed leaf ring and the needs-the-network flags -- against oracle.search (core/MCTS_alphazero.py:144-178), many slots
+from distinct mid-game positions.
+
+(a) the synthetic hash evaluator reading the PACKED leaf batch: visits, Q, root priors, pi bit-exact;
+(b) the fused bf16 tower on the packed + flags path, with the oracle's evaluator callback running the SAME tower on
+    the single dense position: visits and pi bit-exact (the tower is deterministic per board), Q and priors bit-exact too
+    since both sides then see identical logits and values;
+(c) the hand-written f32 tower the same way (the headline's precision).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from .test_gpu_parity import _random_position
+from .test_gpu_tower import _randomised
+
+pytestmark = pytest.mark.gpu
+
+
+def _positions(oracle, G, rng, n=15, max_moves=40):
+    return [_random_position(oracle, 2, n, int(rng.integers(0, max_moves + 1)), rng) for _ in range(G)]
+
+
+def _fix_noise(run, noise_np):
+    t = torch.from_numpy(noise_np)
+
+    def draw():
+        run.noise.copy_(t)
+        return run.noise
+
+    run.draw_noise = draw
+
+
+def _results(eng):
+    G, A = eng.n_slots, eng.dims.n_action
+    visits = eng.new(G, A, dtype=torch.int32)
+    q = eng.new(G, A, dtype=torch.float64)
+    prior = eng.new(G, A)
+    pi = eng.root_policy(visits=visits, child_q=q, root_prior=prior)
+    eng.check()
+    return pi.cpu().numpy(), visits.cpu().numpy(), q.cpu().numpy(), prior.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,G,sims", [(15, 96, 128), (9, 40, 100)])
+def test_runner_search_packed_hash_matches_oracle(oracle, n, G, sims):
+    from alphazero_amd import Engine
+    from alphazero_amd.arena import SelfPlayRunner
+    from alphazero_amd.nets import GomokuNet
+
+    rng = np.random.default_rng(21 + n)
+    eng = Engine(2, G, sims, board_size=n, nn_dtype=torch.bfloat16, device="cuda:0")
+    A = eng.dims.n_action
+    pos = _positions(oracle, G, rng, n)
+    for g, (h, p) in enumerate(pos):
+        eng.set_position(g, h, p)
+    run = SelfPlayRunner(eng, GomokuNet(n, 64, 1).cuda().bfloat16().eval(), sims)
+    scale = 6.0
+    run.evaluate = lambda: eng.eval_hash(None, run.logits, run.values, scale)  # reads the packed leaf batch
+    # make run.search() take the packed route of the fused evaluator: no dense batch is ever written
+    run.fused = object()
+    noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
+    _fix_noise(run, noise_np)
+    run.nn_input.fill_(7.0)
+    run.search()
+    assert bool((run.nn_input == 7.0).all())  # nn_input == NULL all the way
+    pi, visits, q, prior = _results(eng)
+    fn, ctx, _keep = oracle.hash_eval(scale)
+    for g, (h, p) in enumerate(pos):
+        r = oracle.search(2, n, h[-1], p, h, sims, fn, ctx, noise=noise_np[g])
+        assert np.array_equal(visits[g], r["visits"]), g
+        assert np.array_equal(q[g], r["child_q"]), g
+        assert np.array_equal(prior[g], r["root_prior"]), g
+        assert np.array_equal(pi[g], r["pi"]), g
+    st = eng.read_stats()
+    assert st["sims"] == G * sims and st["evals"] + st["terminals"] == st["sims"]
+
+
+def _tower_callback(ev, shape, dtype):
+    """oracle evaluator: the fused tower on ONE dense position (batch 1, the dense-input route of the same kernel)"""
+    from oracle import az_oracle as O
+
+    cin, h, w = shape
+    calls = [0]
+
+    def _cb(_ctx, x, n_in, logits, n_action, value):
+        arr = np.ctypeslib.as_array(x, shape=(n_in,))
+        xt = torch.from_numpy(arr.copy()).view(1, cin, h, w).cuda().to(dtype).contiguous()
+        p, v = ev(xt)
+        np.ctypeslib.as_array(logits, shape=(n_action,))[:] = p.reshape(-1).cpu().numpy()
+        value[0] = float(v.reshape(-1)[0].item())
+        calls[0] += 1
+
+    return O.EVAL_FN(_cb), calls
+
+
+@pytest.mark.parametrize("precision", ["bf16"])
+def test_runner_search_fused_tower_matches_oracle(oracle, precision):
+    """engine + tower on the packed/flags path == oracle + the same tower as its evaluator"""
+    from alphazero_amd import Engine
+    from alphazero_amd.arena import SelfPlayRunner
+    from alphazero_amd.nets import GomokuNet
+
+    n, G, sims = 15, 64, 100
+    rng = np.random.default_rng(5)
+    torch.manual_seed(3)
+    dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+    net = _randomised(GomokuNet(n, 64, 2)).eval().cuda().to(dtype)
+    eng = Engine(2, G, sims, board_size=n, nn_dtype=dtype, device="cuda:0")
+    A = eng.dims.n_action
+    pos = _positions(oracle, G, rng, n)
+    for g, (h, p) in enumerate(pos):
+        eng.set_position(g, h, p)
+    run = SelfPlayRunner(eng, net, sims, fused=True)
+    assert run.fused is not None
+    noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
+    _fix_noise(run, noise_np)
+    run.search()
+    pi, visits, q, prior = _results(eng)
+    d = oracle.dims(2, n)
+    cb, calls = _tower_callback(run.fused, (d["cin"], d["H"], d["W"]), dtype)
+    for g, (h, p) in enumerate(pos):
+        r = oracle.search(2, n, h[-1], p, h, sims, cb, noise=noise_np[g])
+        assert np.array_equal(visits[g], r["visits"]), g
+        assert np.array_equal(pi[g], r["pi"]), g
+        assert np.array_equal(q[g], r["child_q"]), g
+        assert np.array_equal(prior[g], r["root_prior"]), g
+    assert calls[0] == eng.read_stats()["evals"]
+
+
+def test_runner_search_graph_replay_matches_eager(oracle):
+    """the HIP-graph replay of the simulation step (what the small configs run) == the eager loop, bit for bit"""
+    from alphazero_amd import Engine
+    from alphazero_amd.arena import SelfPlayRunner
+    from alphazero_amd.nets import GomokuNet
+
+    n, G, sims = 9, 48, 60
+    rng = np.random.default_rng(9)
+    torch.manual_seed(4)
+    net = _randomised(GomokuNet(n, 64, 2)).eval().cuda().bfloat16()
+    pos = _positions(oracle, G, rng, n, 20)
+    noise_np = rng.dirichlet([0.3] * (n * n), size=G).astype(np.float32)
+    out = []
+    for graph in (False, True):
+        eng = Engine(2, G, sims, board_size=n, nn_dtype=torch.bfloat16, device="cuda:0")
+        for g, (h, p) in enumerate(pos):
+            eng.set_position(g, h, p)
+        run = SelfPlayRunner(eng, net, sims, fused=True, use_graph=graph)
+        _fix_noise(run, noise_np)
+        run.search()
+        out.append(_results(eng))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
