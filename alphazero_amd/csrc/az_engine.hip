@@ -825,6 +825,7 @@ struct az_engine {
 };
 
 static std::string g_create_err;
+int aztower_init_device(int dev);  // az_tower.hip: per-GPU addresses of the library's static device arrays
 
 // Every entry point runs with the engine's GPU current, whatever device the calling thread had selected (a process with
 // several engines, or a caller that never called hipSetDevice), and puts the caller's device back on the way out.
@@ -913,6 +914,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   d.depth_cap = (cfg->max_sims < d.max_plies ? cfg->max_sims : d.max_plies) + 1;
   e->nin = d.nn_channels * d.height * d.width;
   if ((hipSetDevice(cfg->device)) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete e; return AZ_EHIP; }
+  if (aztower_init_device(cfg->device) != AZ_OK) { g_create_err = "looking up the library's static device arrays failed"; delete e; return AZ_EHIP; }
 
   View &v = e->v;
   memset(&v, 0, sizeof(v));

@@ -880,6 +880,36 @@ static unsigned int *tower_tickets(int dev, hipStream_t stream) {
   return t.base + 2 * slot;
 }
 
+// Scratch of az_tower_heads_forward_static (the entry point for callers that cannot allocate): the feature rows that
+// travel from k_tower to k_heads.  One copy per GPU, held until the process ends; `scratch` is only a host-side
+// stand-in for the symbol -- the device address is looked up once per GPU (hipGetSymbolAddress, with that GPU current)
+// and everything below uses that pointer, never the name.
+static __device__ __align__(256) unsigned char scratch[AZ_STATIC_SCRATCH_BYTES];
+static unsigned char *g_scratch_ptr[64];
+
+// -> the scratch of GPU `dev` (which must be current), or nullptr
+static unsigned char *static_scratch(int dev) {
+  std::lock_guard<std::mutex> lock(g_ticket_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || p == nullptr) {
+      (void)hipGetLastError();
+      g_tower_err = "hipGetSymbolAddress(scratch) failed";
+      return nullptr;
+    }
+    g_scratch_ptr[dev] = (unsigned char *)p;
+  }
+  return g_scratch_ptr[dev];
+}
+
+// Called by az_create (the library's set-up call for a GPU) with that GPU current: looks the per-GPU addresses up ahead
+// of the first launch, so that an entry point first called under stream capture has nothing left to resolve.
+int aztower_init_device(int dev) {
+  if (dev < 0 || dev >= 64) return AZ_EINVAL;
+  if (static_scratch(dev) == nullptr) return AZ_EHIP;
+  return tower_tickets(dev, nullptr) != nullptr ? AZ_OK : AZ_EHIP;
+}
+
 extern "C" {
 
 const char *az_tower_last_error(void) { return g_tower_err.c_str(); }
@@ -976,6 +1006,53 @@ int az_tower_forward(int32_t board_size, int32_t channels, int32_t n_boards, int
   err = hipGetLastError();
   if (err != hipSuccess) { g_tower_err = std::string("k_tower launch: ") + hipGetErrorString(err); return AZ_EHIP; }
   return AZ_OK;
+}
+
+int32_t az_static_max_boards(int32_t board_size) {
+  if (board_size != 9 && board_size != 15) return 0;
+  return (int32_t)(AZ_STATIC_SCRATCH_BYTES / ((size_t)az_heads_feat_stride(board_size) * 2));
+}
+
+int az_tower_heads_forward_static(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers,
+                                  const void *x_bf16_dev, const void *packed_ring_dev, const void *packed_leaf_dev,
+                                  const void *flags_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev,
+                                  const float *headw_dev, const float *headb_dev, const void *wp_dev, const float *bp_dev,
+                                  const void *w1_dev, const float *b1_dev, const float *w2_dev, float b2, float *logits_dev,
+                                  float *values_dev, void *stream) {
+  if (board_size != 9 && board_size != 15) { g_tower_err = "board_size must be 9 or 15"; return AZ_EINVAL; }
+  if (n_boards < 1) { g_tower_err = "n_boards >= 1"; return AZ_EINVAL; }
+  const int32_t max_boards = az_static_max_boards(board_size);
+  if (n_boards > max_boards) {
+    g_tower_err = "az_tower_heads_forward_static: n_boards " + std::to_string(n_boards) + " exceeds the static scratch (" +
+                  std::to_string(AZ_STATIC_SCRATCH_BYTES) + " bytes = " + std::to_string(max_boards) + " boards of this size); "
+                  "split the batch or use az_tower_forward + az_heads_forward with a caller-owned buffer";
+    return AZ_EINVAL;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int dev = 0, cur = 0;
+  if (tower_device(s, &dev) != 0 || dev < 0 || dev >= 64) { g_tower_err = "cannot tell the stream's device"; return AZ_EHIP; }
+  if (hipGetDevice(&cur) != hipSuccess) { g_tower_err = "hipGetDevice failed"; return AZ_EHIP; }
+  unsigned char *feat = nullptr;
+  {
+    const bool sw = dev != cur;
+    if (sw) (void)hipSetDevice(dev);
+    feat = static_scratch(dev);  // this GPU's copy of the array (looked up on the first call, or by az_create before)
+    if (sw) (void)hipSetDevice(cur);
+  }
+  if (feat == nullptr) return AZ_EHIP;
+  const int32_t stride = az_heads_feat_stride(board_size);
+  // the array keeps the last call's contents (another board size has another row layout): the pad columns the kernels
+  // never write, and the rows of slots the tower skips, must read as zero
+  if (hipMemsetAsync(feat, 0, (size_t)n_boards * stride * 2, s) != hipSuccess) {
+    g_tower_err = "hipMemsetAsync(scratch) failed";
+    (void)hipGetLastError();
+    return AZ_EHIP;
+  }
+  int rc = az_tower_forward(board_size, channels, n_boards, n_conv_layers, x_bf16_dev, packed_ring_dev, packed_leaf_dev, nullptr,
+                            nullptr, flags_dev, w0_dev, wl_dev, bias_dev, headw_dev, headb_dev, feat, stride, stream);
+  if (rc != AZ_OK) return rc;
+  return az_heads_forward(board_size, n_boards, feat, stride, wp_dev, bp_dev, w1_dev, b1_dev, w2_dev, b2, logits_dev, values_dev,
+                          stream);
 }
 
 }  // extern "C"

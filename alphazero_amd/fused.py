@@ -159,3 +159,29 @@ class FusedTowerEvaluator:
             raise EngineError(f"az_heads_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
         value = value.view(B, 1)
         return logits, value
+
+    def forward_static(self, x: torch.Tensor | None, logits: torch.Tensor, values: torch.Tensor, packed=None, n_boards: int = 0):
+        """The same evaluation through az_tower_heads_forward_static: nothing is allocated -- not here (the caller owns
+        ``logits`` (B, N*N) and ``values`` (B,) f32) and not in the library (the feature rows between the two kernels live
+        in its static per-GPU array).  B is limited to ``az_static_max_boards``; calls on one GPU must not overlap."""
+        if x is not None:
+            if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
+                raise EngineError("forward_static expects a contiguous (B,9,N,N) bf16 batch on the model's GPU")
+            B, ring_p, leaf_p, flags_p = x.shape[0], None, None, None
+        else:
+            if packed is None or n_boards < 1:
+                raise EngineError("forward_static: give either x or packed=(ring, leaf[, list, count, flags]) with n_boards")
+            B, ring_p, leaf_p = n_boards, C.c_void_p(packed[0]), C.c_void_p(packed[1])
+            flags_p = C.c_void_p(packed[4]) if len(packed) > 4 and packed[4] else None
+        for t, shape in ((logits, (B, self.n2)), (values, (B,))):
+            if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape or t.device != self.device:
+                raise EngineError(f"forward_static: outputs must be contiguous float32 {shape} tensors on the model's GPU")
+        P = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self.lib.az_tower_heads_forward_static(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p,
+                                                    leaf_p, flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.headw),
+                                                    P(self.headb), P(self.wp), P(self.bp), P(self.w1), P(self.b1), P(self.w2),
+                                                    self.b2, P(logits), P(values), st)
+        if rc != 0:
+            raise EngineError(f"az_tower_heads_forward_static failed ({rc}): {self.lib.az_tower_last_error().decode()}")
+        return logits, values

@@ -235,6 +235,24 @@ int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16
                      float *logits_dev, float *values_dev, void *stream);
 const char *az_tower_last_error(void);
 
+/* No counterpart in the reference.  For callers that CANNOT allocate device memory around the evaluation -- code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: az_tower_forward followed by
+ * az_heads_forward in one call, with the feature rows that travel between the two kernels kept in a static array
+ * inside the library (AZ_STATIC_SCRATCH_BYTES per GPU, held until the process ends) instead of a caller-owned
+ * feat buffer.  Arguments as for those two calls (flags_dev may be NULL; there is no list mode); the caller still
+ * passes inputs, weights and the logits / values outputs.  Calls no hipMalloc / hipFree and no allocating library
+ * routine.  n_boards above az_static_max_boards(board_size) (4,468 boards of 15x15, 11,565 of 9x9) is refused with
+ * AZ_EINVAL and a message in az_tower_last_error().  Every call on a GPU shares that GPU's array: calls that overlap in
+ * time on one GPU (two streams, two threads) race -- serialise them. */
+#define AZ_STATIC_SCRATCH_BYTES (6u << 20)
+int32_t az_static_max_boards(int32_t board_size);
+int az_tower_heads_forward_static(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers,
+                                  const void *x_bf16_dev, const void *packed_ring_dev, const void *packed_leaf_dev,
+                                  const void *flags_dev, const void *w0_dev, const void *wl_dev, const float *bias_dev,
+                                  const float *headw_dev, const float *headb_dev, const void *wp_dev, const float *bp_dev,
+                                  const void *w1_dev, const float *b1_dev, const float *w2_dev, float b2, float *logits_dev,
+                                  float *values_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
