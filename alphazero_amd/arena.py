@@ -82,9 +82,10 @@ class SelfPlayRunner:
         if fused:  # hand-written MFMA conv tower (csrc/az_tower.hip) instead of the module's own forward
             from .fused import FusedTowerEvaluator
 
-            if engine.nn_dtype != torch.bfloat16:
-                raise EngineError("the fused evaluator reads a bf16 batch: create the engine with nn_dtype=torch.bfloat16")
-            self.fused = FusedTowerEvaluator(model)
+            if engine.nn_dtype not in (torch.bfloat16, torch.float32):
+                raise EngineError("the fused evaluator exists in bf16 and f32: create the engine with one of these nn_dtypes")
+            # the engine's nn_dtype decides: f32 = the reference's own arithmetic (az_tower_f32.hip), bf16 = throughput mode
+            self.fused = FusedTowerEvaluator(model, "f32" if engine.nn_dtype == torch.float32 else "bf16")
             if engine.game != GAME_GOMOKU or self.fused.board != engine.dims.height:
                 raise EngineError("the fused evaluator's board does not match the engine's game")
             ring, leaf, _, _, flags = engine.leaf_buffers()

@@ -814,6 +814,7 @@ __global__ __launch_bounds__(256, 2) void k_heads(const uint16_t *__restrict__ f
 }  // namespace aztower
 
 static thread_local std::string g_tower_err;  // per host thread: engines on different threads do not share (or race on) a message
+void tower_set_error(const std::string &msg) { g_tower_err = msg; }  // (az_tower_f32.hip reports through the same az_tower_last_error)
 
 // Ticket counters of the tower launches: {next group, workgroups done} pairs, zero at load and re-armed by each launch's
 // last workgroup, so a pair is free again as soon as its launch has ended.  Two launches may share a pair only if they
@@ -840,7 +841,7 @@ struct TicketDev {
 static TicketDev g_td[64];
 
 // the device a launch on `stream` runs on (the current device for the NULL stream)
-static int tower_device(hipStream_t stream, int *dev) {
+int tower_device(hipStream_t stream, int *dev) {  // (also used by az_tower_f32.hip)
   hipDevice_t d = 0;
   if (stream != nullptr && hipStreamGetDevice(stream, &d) == hipSuccess) { *dev = (int)d; return 0; }
   (void)hipGetLastError();
@@ -848,7 +849,7 @@ static int tower_device(hipStream_t stream, int *dev) {
 }
 
 // -> the ticket pair of this launch, or nullptr (message in g_tower_err).  `dev` is current.
-static unsigned int *tower_tickets(int dev, hipStream_t stream) {
+unsigned int *tower_tickets(int dev, hipStream_t stream) {  // (also used by az_tower_f32.hip)
   std::lock_guard<std::mutex> lock(g_ticket_mutex);
   TicketDev &t = g_td[dev];
   if (t.base == nullptr) {

@@ -1,0 +1,516 @@
+// az_tower_f32.hip -- the residual conv tower and the heads' Linear layers in FLOAT32, for MI355X (gfx950).
+//
+// The reference evaluates its network in f32 (nn_models/base.py:17-19, core/MCTS_alphazero.py:161-162: no autocast), so
+// this is the evaluator at the reference's own precision; az_tower.hip is the bf16 throughput version of the same tower.
+// Same network family (examples/gomoku/model.py:41-90: conv3x3(9->64)+BN+ReLU, residual blocks of two conv3x3(64->64)+BN,
+// the 1x1 head convs+BN+ReLU, then the heads' Linear layers), same structure of the kernel: one workgroup (4 waves) owns
+// one 15x15 board (three 9x9 boards) for the whole tower, activations resident in LDS, every conv an implicit GEMM
+//   D[co][cell] = sum_{tap, ci} W[co][tap][ci] * X[ci][cell + shift(tap)]
+// on v_mfma_f32_32x32x2_f32 (f32 operands, f32 accumulate: bit for bit a k-ordered fmaf chain; dense peak 157.3 TFLOP/s
+// = 1/16 of the bf16 rate, so the MFMA pipe -- not LDS, not the weight stream -- is what bounds this kernel by a wide margin).
+//
+// LDS: act[cell][64] f32, 256 B per cell, the sixteen 16-byte channel chunks of a cell XOR-swizzled with (cell & 15): the
+// 32 lanes of a cell tile hold 32 consecutive cells, a tap shifts all of them by the same amount, so the 16 lanes of a
+// ds_read_b128 group hit 16 different bank quads.  Taps that fall off the board read a 256-byte zero row.
+// One ds_read_b128 feeds FOUR MFMAs: the instruction wants A[co][k = lane>>5] / B[k = lane>>5][cell], one float each; a
+// lane of half h reads channels 8m + 4h .. 8m + 4h + 3 and MFMA t of "k-step" m takes element t, i.e. the k pair
+// {8m + t, 8m + 4 + t} -- any pairing works as long as weights and activations agree.
+// Weights: [tap][k-step][half][co 64][4 ci] f32 in global memory = the order the LDS stage holds them (a lane's A read is
+// 16 B at co * 16: conflict free), streamed 4 k-steps (8 KiB) at a time by LDS-DMA, double buffered, under the MFMAs.
+// Per wave: 2 cell tiles x 2 channel tiles of 32x32 = 64 accumulator registers; the layer is computed in place (outputs
+// wait in the accumulators until every wave has read the input); the block's residual stays in registers as f32.
+// Boards are handed out by the library's ticket counter (az_tower.hip); the input is the engine's packed leaf batch
+// (8 bitboards + player) or dense f32 planes.  C ABI at the bottom; declared in include/az_engine.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/az_engine.h"
+
+int tower_device(hipStream_t stream, int *dev);             // az_tower.hip
+unsigned int *tower_tickets(int dev, hipStream_t stream);   // az_tower.hip
+void tower_set_error(const std::string &msg);               // az_tower.hip
+
+namespace aztf32 {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int C = 64;               // trunk width
+constexpr int ROW = 4 * C;          // bytes per cell
+constexpr int KSB = 2 * C * 16;     // bytes of one k-step of weights: [half 2][co 64][4 ci] f32 = 2 KiB
+constexpr int KPS = 4;              // k-steps per stage of a 64 -> 64 layer (8 KiB; 18 stages per layer)
+constexpr int KPS0 = 2;             // ... of the stem (9 channels padded to 16 = 2 k-steps per tap: one tap per stage)
+constexpr int STAGE_BYTES = KPS * KSB;
+constexpr int NPT = 2;              // 32-cell tiles per wave
+
+template <int N, int BPW>
+struct GeoF {
+  static constexpr int NV = N * N, NVT = BPW * NV;
+  static constexpr int ZERO_OFF = NVT * ROW;
+  static constexpr int ACT_BYTES = NVT * ROW + ROW;
+  static constexpr int HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16;
+  static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = BPW * 8 * SWB;  // packed input words per group
+  static constexpr int RG_BYTES = ((RGW + 2 * BPW + 1) * 4 + 15) / 16 * 16;     // ring words, BPW players, BPW slots, the ticket
+  static_assert(NVT <= 4 * NPT * 32, "4 waves x 2 tiles of 32 cells");
+  static constexpr size_t lds_bytes() { return (size_t)ACT_BYTES + 2 * STAGE_BYTES + HW_BYTES + RG_BYTES; }
+};
+
+__device__ __forceinline__ int act_addr(int p, int chunk) { return p * ROW + ((chunk ^ (p & 15)) << 4); }
+
+// async global -> LDS copy of 16 B per lane: the LDS destination is the wave-uniform `lds_base` + lane * 16
+__device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
+                                   (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)lds_base, 16, 0, 0);
+}
+
+// `bytes` (a multiple of 4 KiB) of weights, contiguous in global memory and in the LDS stage alike: 1 KiB per
+// wave-instruction, wave w moves pieces w, w + 4, ...
+template <int BYTES>
+__device__ __forceinline__ void stage_w(const char *src, char *dst, int wave, int lane) {
+  static_assert(BYTES % 4096 == 0, "whole rounds of the four waves");
+#pragma unroll
+  for (int p = 0; p < BYTES / 4096; ++p) glds16(src + (p * 4 + wave) * 1024 + lane * 16, dst + (p * 4 + wave) * 1024);
+}
+
+// One conv layer: acc[pt][ct] += W * X.  KS = k-steps (8 input channels each) per tap, KPSL = k-steps per stage.
+// On entry stage 0 of THIS layer is already in buffer `buf` (landed and barriered); during the last stage the first stage
+// of the NEXT layer (wnext, NEXT_BYTES; nullptr = none) is prefetched.  Every stage ends with a barrier, so after the
+// last one every wave has finished reading act and the epilogue may overwrite it.  The k-steps of a stage are software
+// pipelined through two register sets (the four fragment reads of step i + 1 are issued before the 16 MFMAs of step i).
+template <int KS, int KPSL, int NEXT_BYTES, int N, int ZERO_OFF>
+__device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext, int wave,
+                                           int lane, const int (&pp)[NPT], const uint32_t (&vm)[NPT], f32x16 (&acc)[NPT][2]) {
+  static_assert(KS % KPSL == 0, "a stage never straddles two taps");
+  constexpr int SPT = KS / KPSL, NSTAGE = 9 * SPT, SB = KPSL * KSB;
+  const int h = lane >> 5, r = lane & 31;
+  const uint32_t act32 = (uint32_t)(uintptr_t)act;
+#pragma unroll 1
+  for (int sg = 0; sg < NSTAGE; ++sg) {
+    const int tap = sg / SPT, ks0 = (sg % SPT) * KPSL;
+    const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
+    uint32_t bb[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+      const uint32_t q = (uint32_t)(pp[pt] + d);
+      const uint32_t in = (q << 8) | (((q & 15u) ^ (uint32_t)h) << 4);
+      bb[pt] = ((vm[pt] >> tap) & 1u) ? in : (uint32_t)(ZERO_OFF | (h << 4));
+    }
+    const uint32_t wa32 = (uint32_t)(uintptr_t)(wbuf + ((buf + sg) & 1) * STAGE_BYTES + h * (C * 16) + r * 16);
+    f32x4 fa[2][2], fb[2][NPT];
+    auto load = [&](int i, int s) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][0]) : "v"(wa32), "i"(i * KSB));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][1]) : "v"(wa32), "i"(i * KSB + 512));
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][pt]) : "v"(act32 + (bb[pt] ^ (uint32_t)((ks0 + i) << 5))));
+    };
+    load(0, 0);
+#pragma unroll
+    for (int i = 0; i < KPSL; ++i) {
+      if (i + 1 < KPSL) {
+        load(i + 1, (i + 1) & 1);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // step i's four reads have returned
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+          acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i & 1][0][t], fb[i & 1][pt][t], acc[pt][0], 0, 0, 0);
+          acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i & 1][1][t], fb[i & 1][pt][t], acc[pt][1], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 0) {  // the DMA of the next stage's weights: issued under this stage's MFMAs
+        char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
+        if (sg < NSTAGE - 1) stage_w<SB>(wg + (size_t)(sg + 1) * SB, wn, wave, lane);
+        else if (wnext != nullptr) stage_w<NEXT_BYTES>(wnext, wn, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next stage has landed
+    __syncthreads();
+  }
+  buf = (buf + NSTAGE) & 1;
+}
+
+// acc[pt][ct][4q + j] = channel ct*32 + 8q + 4h + j of cell pp[pt]  (C/D map of the 32x32 MFMAs: row = (reg & 3) + 8 (reg >> 2) + 4 h)
+template <bool RES>
+__device__ __forceinline__ void init_acc(const float *__restrict__ bias, int lane, f32x16 (&acc)[NPT][2], const f32x4 (&res)[NPT][2][4]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *(const f32x4 *)(bias + ct * 32 + q * 8 + h * 4);
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[pt][ct][4 * q + j] = RES ? b[j] + res[pt][ct][q][j] : b[j];
+    }
+}
+
+__device__ __forceinline__ void epilogue(char *act, int lane, const int (&pp)[NPT], const bool (&ok)[NPT], const f32x16 (&acc)[NPT][2]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[pt][ct][4 * q + j], 0.0f);
+        if (ok[pt]) *(f32x4 *)(act + act_addr(pp[pt], ct * 8 + 2 * q + h)) = v;
+      }
+}
+
+// x: (G, 9, N, N) f32, or nullptr to read the engine's packed leaf batch (ring u32 (G,8,SWB) + leaf records).
+// w0: [9 taps][2][2][64][4] f32 (9 input channels padded to 16).  wl: [L][9][8][2][64][4] f32.  bias: [1+L][64] f32.
+// headw: [3][64] f32 (policy, value0, value1), headb: [3].  feat: (G, FS) f32 = the heads' Linear inputs,
+// row layout [policy NV | pad to 16 | value0 NV | value1 NV | pad to 16] (pads are never written).
+template <int N, int BPW>
+__global__ __launch_bounds__(256, 2) void k_tower_f32(const float *__restrict__ x, const uint32_t *__restrict__ ring,
+                                                      const int4 *__restrict__ leafrec, const uint8_t *__restrict__ flags, int G,
+                                                      const char *__restrict__ w0, const char *__restrict__ wl,
+                                                      const float *__restrict__ bias, int L, const float *__restrict__ headw,
+                                                      const float *__restrict__ headb, float *__restrict__ feat, int FS,
+                                                      unsigned int *tickets) {
+  using Q = GeoF<N, BPW>;
+  constexpr int NV = Q::NV, NVT = Q::NVT, WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *act = smem;
+  char *wbuf = smem + Q::ACT_BYTES;
+  float *hw = (float *)(wbuf + 2 * STAGE_BYTES);
+  uint32_t *rg = (uint32_t *)((char *)hw + Q::HW_BYTES);  // RGW ring words, BPW players, BPW slots, the ticket
+  int *slots = (int *)rg + RGW + BPW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  for (int i = tid; i < Q::ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero row
+  for (int i = tid; i < 3 * C + 3; i += 256) hw[i] = i < 3 * C ? headw[i] : headb[i - 3 * C];
+
+  int pp[NPT];
+  bool ok[NPT];
+  uint32_t vm[NPT];
+#pragma unroll
+  for (int pt = 0; pt < NPT; ++pt) {
+    const int m = (NPT * wave + pt) * 32 + (lane & 31);
+    ok[pt] = m < NVT;
+    pp[pt] = ok[pt] ? m : 0;
+    const int cell = pp[pt] % NV, row = cell / N, col = cell % N;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int rr = row + t / 3 - 1, cc = col + t % 3 - 1;
+      if (rr >= 0 && rr < N && cc >= 0 && cc < N) mask |= 1u << t;
+    }
+    vm[pt] = ok[pt] ? mask : 0u;
+  }
+  const int ngroups = (G + BPW - 1) / BPW;
+  int buf = 0;
+  stage_w<KPS0 * KSB>(w0, wbuf, wave, lane);  // the stem's first stage (kept in flight across the first ticket draw)
+  int ticket = (int)blockIdx.x;                // the first gridDim.x groups go by block index, the counter hands out the rest
+
+  for (;;) {
+    // ---- this workgroup's next group of BPW consecutive slots; in flag mode only the flagged ones are evaluated
+    __syncthreads();  // (everybody is done with rg / slots of the previous group)
+    if (tid == 0) {
+      for (;;) {
+        bool any = false;
+        if (ticket < ngroups) {
+          for (int b = 0; b < BPW; ++b) {
+            const int g = ticket * BPW + b;
+            const bool on = g < G && (flags == nullptr || flags[g] != 0);
+            slots[b] = on ? g : -1;
+            any |= on;
+          }
+        }
+        if (any || ticket >= ngroups) break;
+        ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));  // a group of terminal leaves: one more draw
+      }
+      slots[BPW] = ticket;
+    }
+    __syncthreads();
+    if (slots[BPW] >= ngroups) break;
+    if (tid == 0) ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));  // the next group's ticket: arrives under this group's tower
+    if (x == nullptr) {
+      for (int i = tid; i < RGW + BPW; i += 256) {
+        const int b = i < RGW ? i / (8 * SWB) : i - RGW, g = slots[b];
+        uint32_t v = 0;
+        if (g >= 0) v = i < RGW ? ring[(size_t)g * 8 * SWB + i % (8 * SWB)] : (uint32_t)leafrec[g].w;
+        rg[i] = v;
+      }
+      __syncthreads();
+    }
+    // ---- input -> act[cell][0..15] (channels 9..15 zero)
+    for (int m = tid; m < NVT; m += 256) {
+      const int b = m / NV, cell = m % NV, g = slots[b];
+      float c[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) c[k] = 0.0f;
+      if (g >= 0) {
+        if (x != nullptr) {
+          const float *xr = x + (size_t)g * 9 * NV + cell;
+#pragma unroll
+          for (int ch = 0; ch < 9; ++ch) c[ch] = xr[ch * NV];
+        } else {
+          const uint32_t *rb = rg + b * 8 * SWB;
+          const int wi = cell >> 5, sh = cell & 31;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            c[k] = (float)(int)((rb[k * SWB + wi] >> sh) & 1u) - (float)(int)((rb[k * SWB + WC + wi] >> sh) & 1u);
+          c[8] = (int)rg[RGW + b] > 0 ? 1.0f : -1.0f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *(f32x4 *)(act + act_addr(m, k)) = (f32x4){c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (first group: the stem's first weight stage)
+    __syncthreads();
+
+    f32x16 acc[NPT][2];
+    f32x4 res[NPT][2][4];
+    // ---- stem
+    init_acc<false>(bias, lane, acc, res);
+    if (L > 0) conv_layer<2, KPS0, KPS * KSB, N, Q::ZERO_OFF>(act, wbuf, buf, w0, wl, wave, lane, pp, vm, acc);
+    else conv_layer<2, KPS0, KPS0 * KSB, N, Q::ZERO_OFF>(act, wbuf, buf, w0, w0, wave, lane, pp, vm, acc);
+    if (L > 0) {
+      epilogue(act, lane, pp, ok, acc);
+      __syncthreads();
+    }
+    // ---- residual blocks
+    for (int l = 0; l < L; l += 2) {
+      {
+        const int h = lane >> 5;
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const f32x4 *)(act + act_addr(pp[pt], ct * 8 + 2 * q + h));
+      }
+      init_acc<false>(bias + (1 + l) * C, lane, acc, res);
+      conv_layer<8, KPS, KPS * KSB, N, Q::ZERO_OFF>(act, wbuf, buf, wl + (size_t)l * 9 * 8 * KSB, wl + (size_t)(l + 1) * 9 * 8 * KSB, wave, lane,
+                                                    pp, vm, acc);
+      epilogue(act, lane, pp, ok, acc);
+      __syncthreads();
+      init_acc<true>(bias + (2 + l) * C, lane, acc, res);
+      if (l + 2 < L) {
+        conv_layer<8, KPS, KPS * KSB, N, Q::ZERO_OFF>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * 8 * KSB, wl + (size_t)(l + 2) * 9 * 8 * KSB, wave,
+                                                      lane, pp, vm, acc);
+        epilogue(act, lane, pp, ok, acc);
+        __syncthreads();
+      } else {  // the tower's last layer: its output stays in the accumulators for the heads; prefetch the next board's stem
+        conv_layer<8, KPS, KPS0 * KSB, N, Q::ZERO_OFF>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * 8 * KSB, w0, wave, lane, pp, vm, acc);
+      }
+    }
+    // ---- heads: the three 1x1 convs (+ folded BN) + ReLU from the last layer's accumulators (a lane holds 32 of its cell's 64
+    // channels, the other 32 sit in lane ^ 32), then the f32 rows of the heads' Linear inputs
+    {
+      const int h = lane >> 5;
+      float hs[NPT][3];
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) hs[pt][0] = hs[pt][1] = hs[pt][2] = 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 wv[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) wv[k] = *(const f32x4 *)(hw + k * C + ct * 32 + q * 8 + h * 4);
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float a = fmaxf(acc[pt][ct][4 * q + j], 0.0f);
+#pragma unroll
+              for (int k = 0; k < 3; ++k) hs[pt][k] = fmaf(a, wv[k][j], hs[pt][k]);
+            }
+        }
+      constexpr int KP = (NV + 15) / 16 * 16;
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+        float t[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // lower half's sum + upper half's, in that order on both halves
+          const float other = __shfl_xor(hs[pt][k], 32, 64);
+          t[k] = h == 0 ? hs[pt][k] + other : other + hs[pt][k];
+        }
+        if ((pt & 1) != h || !ok[pt]) continue;  // even tiles are written by the lower half-wave, odd ones by the upper
+        const int cell = pp[pt] % NV, g = slots[pp[pt] / NV];
+        if (g < 0) continue;
+        float *fr = feat + (size_t)g * FS;
+        fr[cell] = fmaxf(t[0] + hw[3 * C + 0], 0.0f);
+        fr[KP + cell] = fmaxf(t[1] + hw[3 * C + 1], 0.0f);
+        fr[KP + NV + cell] = fmaxf(t[2] + hw[3 * C + 2], 0.0f);
+      }
+    }
+  }
+  // past the end: report in; the last workgroup to do so re-arms the counters for the next launch
+  if (tid == 0 && atomicAdd(&tickets[1], 1u) == gridDim.x - 1) {
+    tickets[0] = 0u;
+    tickets[1] = 0u;
+    __threadfence();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The heads' Linear layers in f32 (examples/gomoku/model.py:69-90): logits = feat[:, :NV] @ Wp^T + bp;
+// value = tanh(relu(feat[:, KP:KP+2NV] @ W1^T + b1) @ w2 + b2), as f32 MFMA GEMMs read straight from L2.  One workgroup = 32
+// boards x one job (blockIdx.y: four policy output tiles, one per wave | the value head).  A = features (lane: board
+// l & 31, k half l >> 5: one 16-byte load = the lane's operands of four MFMAs), B = weights packed
+// [n-tile][k-step][half][n 32][4 k] f32, zero padded.
+template <int NV>
+__global__ __launch_bounds__(256, 2) void k_heads_f32(const float *__restrict__ feat, int FS, int G, const char *__restrict__ wp,
+                                                      const float *__restrict__ bp, const char *__restrict__ w1,
+                                                      const float *__restrict__ b1, const float *__restrict__ w2, float b2,
+                                                      float *__restrict__ logits, float *__restrict__ values) {
+  constexpr int KP = (NV + 15) / 16 * 16, KSP = KP / 8, NTP = (NV + 31) / 32;
+  constexpr int KV = (2 * NV + 15) / 16 * 16, KSV = KV / 8, KH = KSV / 2;
+  __shared__ float part[4][32][33];
+  __shared__ float vsum[2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int g0 = blockIdx.x * 32;
+  const float *fa = feat + (size_t)min(g0 + r, G - 1) * FS + 4 * h;  // rows past the batch: a copy of the last row, not stored
+  constexpr int PB = (NTP + 3) / 4;
+  const int job = blockIdx.y;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  if (job < PB) {
+    const int nt = job * 4 + wave;
+    if (nt >= NTP) return;
+    const char *wb = wp + ((size_t)nt * KSP * 2 + h) * 512 + r * 16;
+#pragma unroll 6
+    for (int ks = 0; ks < KSP; ++ks) {
+      const f32x4 b = *(const f32x4 *)(wb + (size_t)ks * 1024);
+      const f32x4 a = *(const f32x4 *)(fa + ks * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+    const int n = nt * 32 + r;
+    if (n < NV) {
+      const float bias = bp[n];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (g0 + row < G) logits[(size_t)(g0 + row) * NV + n] = acc[i] + bias;
+      }
+    }
+    return;
+  }
+  {  // value: hidden tile (wave & 1), K half (wave >> 1)
+    const int nt = wave & 1, kh = wave >> 1;
+    const char *wb = w1 + ((size_t)nt * KSV * 2 + h) * 512 + r * 16;
+#pragma unroll 6
+    for (int k = 0; k < KH; ++k) {
+      const int ks = kh * KH + k;
+      const f32x4 b = *(const f32x4 *)(wb + (size_t)ks * 1024);
+      const f32x4 a = *(const f32x4 *)(fa + KP + ks * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i];
+    __syncthreads();
+    if (wave < 2) {
+      const int n = wave * 32 + r;
+      const float bn = b1[n], wn = w2[n];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        float t = fmaxf(part[wave][row][r] + part[wave + 2][row][r] + bn, 0.0f) * wn;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (r == 0) vsum[wave][row] = t;
+      }
+    }
+    __syncthreads();
+    if (tid < 32 && g0 + tid < G) values[g0 + tid] = tanhf(vsum[0][tid] + vsum[1][tid] + b2);
+  }
+}
+
+}  // namespace aztf32
+
+static std::mutex g_f32_mutex;
+static unsigned int g_f32_attr_done[64];
+
+extern "C" {
+
+int az_heads_forward_f32(int32_t board_size, int32_t n_boards, const float *feat_dev, int32_t feat_stride, const void *wp_dev,
+                         const float *bp_dev, const void *w1_dev, const float *b1_dev, const float *w2_dev, float b2,
+                         float *logits_dev, float *values_dev, void *stream) {
+  using namespace aztf32;
+  if (!feat_dev || !wp_dev || !bp_dev || !w1_dev || !b1_dev || !w2_dev || !logits_dev || !values_dev) { tower_set_error("null argument"); return AZ_EINVAL; }
+  if (n_boards < 1 || (board_size != 9 && board_size != 15)) { tower_set_error("n_boards >= 1, board_size 9 or 15"); return AZ_EINVAL; }
+  if (feat_stride < az_heads_feat_stride(board_size) || (feat_stride & 3)) { tower_set_error("feat_stride: a multiple of 4, at least az_heads_feat_stride(board_size)"); return AZ_EINVAL; }
+  const int ntp = (board_size * board_size + 31) / 32;
+  const dim3 grid((n_boards + 31) / 32, (ntp + 3) / 4 + 1), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (board_size == 15)
+    hipLaunchKernelGGL((k_heads_f32<225>), grid, block, 0, s, feat_dev, (int)feat_stride, (int)n_boards, (const char *)wp_dev, bp_dev,
+                       (const char *)w1_dev, b1_dev, w2_dev, b2, logits_dev, values_dev);
+  else
+    hipLaunchKernelGGL((k_heads_f32<81>), grid, block, 0, s, feat_dev, (int)feat_stride, (int)n_boards, (const char *)wp_dev, bp_dev,
+                       (const char *)w1_dev, b1_dev, w2_dev, b2, logits_dev, values_dev);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) { tower_set_error(std::string("k_heads_f32 launch: ") + hipGetErrorString(err)); return AZ_EHIP; }
+  return AZ_OK;
+}
+
+int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const float *x_f32_dev,
+                         const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev, const void *w0_dev,
+                         const void *wl_dev, const float *bias_dev, const float *headw_dev, const float *headb_dev, float *feat_f32_dev,
+                         int32_t feat_stride, void *stream) {
+  using namespace aztf32;
+  if ((!x_f32_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !feat_f32_dev ||
+      (n_conv_layers > 0 && !wl_dev)) { tower_set_error("null argument"); return AZ_EINVAL; }
+  if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1)) { tower_set_error("n_boards >= 1, even n_conv_layers"); return AZ_EINVAL; }
+  if ((board_size != 9 && board_size != 15) || channels != 64) { tower_set_error("f32 tower: board_size 9 or 15, 64 channels"); return AZ_EINVAL; }
+  if (feat_stride < az_heads_feat_stride(board_size)) { tower_set_error("feat_stride below az_heads_feat_stride(board_size)"); return AZ_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  int dev = 0, cur = 0;
+  if (tower_device(s, &dev) != 0 || dev < 0 || dev >= 64) { tower_set_error("cannot tell the stream's device"); return AZ_EHIP; }
+  if (hipGetDevice(&cur) != hipSuccess) { tower_set_error("hipGetDevice failed"); return AZ_EHIP; }
+  struct DeviceGuard {
+    int back;
+    DeviceGuard(int want, int cur_) : back(want != cur_ ? cur_ : -1) { if (back >= 0) (void)hipSetDevice(want); }
+    ~DeviceGuard() { if (back >= 0) (void)hipSetDevice(back); }
+  } guard(dev, cur);
+  unsigned int *tickets = tower_tickets(dev, s);
+  if (tickets == nullptr) return AZ_EHIP;
+  auto launch = [&](auto kern, size_t lds, int bpw, int variant) -> int {
+    if (lds * 2 > 160 * 1024) { tower_set_error("f32 tower geometry exceeds the CU's LDS"); return AZ_EINVAL; }
+    {
+      std::lock_guard<std::mutex> lock(g_f32_mutex);
+      if (!(g_f32_attr_done[dev] & (1u << variant))) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          tower_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+          return AZ_EHIP;
+        }
+        g_f32_attr_done[dev] |= 1u << variant;
+      }
+    }
+    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * 2;  // two workgroups per CU
+    const int grid = groups < cap ? groups : cap;
+    const bool use_flags = !x_f32_dev && flags_dev;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, x_f32_dev, (const uint32_t *)packed_ring_dev, (const int4 *)packed_leaf_dev,
+                       (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
+                       n_conv_layers, headw_dev, headb_dev, feat_f32_dev, (int)feat_stride, tickets);
+    return AZ_OK;
+  };
+  int rc;
+  if (board_size == 15) rc = launch(k_tower_f32<15, 1>, GeoF<15, 1>::lds_bytes(), 1, 0);
+  else rc = launch(k_tower_f32<9, 3>, GeoF<9, 3>::lds_bytes(), 3, 1);
+  if (rc != AZ_OK) return rc;
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) { tower_set_error(std::string("k_tower_f32 launch: ") + hipGetErrorString(err)); return AZ_EHIP; }
+  return AZ_OK;
+}
+
+}  // extern "C"

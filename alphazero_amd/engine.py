@@ -41,7 +41,7 @@ EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check"
            "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_expand_select", "az_root_policy",
            "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
            "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_heads_forward", "az_heads_feat_stride", "az_augment_samples", "az_leaf_buffers", "az_compact_leaves", "az_copy_to_host",
-           "az_tower_heads_forward_static", "az_static_max_boards"]
+           "az_tower_heads_forward_static", "az_static_max_boards", "az_tower_forward_f32", "az_heads_forward_f32"]
 
 _lib = None
 
@@ -89,6 +89,8 @@ def load_library() -> C.CDLL:
     lib.az_static_max_boards.argtypes = [C.c_int32]
     lib.az_static_max_boards.restype = C.c_int32
     lib.az_tower_heads_forward_static.argtypes = [C.c_int32] * 4 + [vp] * 14 + [C.c_float, vp, vp, vp]
+    lib.az_tower_forward_f32.argtypes = [C.c_int32] * 4 + [vp] * 10 + [C.c_int32, vp]
+    lib.az_heads_forward_f32.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
     for name in EXPORTS:

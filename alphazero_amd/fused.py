@@ -42,6 +42,24 @@ def _pack_linear(w: torch.Tensor, n_pad: int, k_pad: int, k_off_src: int = 0) ->
     return t.permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16)
 
 
+def _pack3x3_f32(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
+    """(co, ci, 3, 3) f32 -> [tap 9][k-step ci/8][half 2][co][4] f32 (csrc/az_tower_f32.hip)"""
+    co, ci = w.shape[0], w.shape[1]
+    if ci < cin_pad:
+        w = torch.cat([w, w.new_zeros(co, cin_pad - ci, 3, 3)], 1)
+    t = w.permute(2, 3, 1, 0).reshape(9, cin_pad // 8, 2, 4, co)  # tap, ks, half, j, co
+    return t.permute(0, 1, 2, 4, 3).contiguous().float()
+
+
+def _pack_linear_f32(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
+    """(n, k) f32 Linear weight -> [n-tile][k-step k/8][half 2][n 32][4 k] f32, zero padded to (n_pad, k_pad)"""
+    n, k = w.shape
+    full = w.new_zeros(n_pad, k_pad)
+    full[:n, :k] = w
+    t = full.reshape(n_pad // 32, 32, k_pad // 8, 2, 4)  # nt, n, ks, half, j
+    return t.permute(0, 2, 3, 1, 4).contiguous().float()
+
+
 class FusedTowerEvaluator:
     @staticmethod
     def supports(model: nn.Module) -> bool:
@@ -61,7 +79,10 @@ class FusedTowerEvaluator:
         except Exception:
             return False
 
-    def __init__(self, model: nn.Module):
+    def __init__(self, model: nn.Module, precision: str = "bf16"):
+        """precision: "bf16" (az_tower.hip: bf16 operands, f32 accumulation -- the throughput mode) or "f32"
+        (az_tower_f32.hip: f32 MFMA, the reference's own arithmetic, 64-channel trunks).  The weights are folded and
+        packed from the module's parameters in f32 either way, whatever dtype the module itself holds."""
         if not self.supports(model):
             raise EngineError("FusedTowerEvaluator: not a GomokuModel-family network (64- or 128-channel 3x3 residual tower)")
         self.lib = load_library()
@@ -72,6 +93,12 @@ class FusedTowerEvaluator:
         self.n2 = model._policy_head[4].in_features
         self.board = 15 if self.n2 == 225 else 9
         self.ch = model._shared_layers[0].out_channels
+        if precision not in ("bf16", "f32"):
+            raise EngineError("FusedTowerEvaluator: precision must be 'bf16' or 'f32'")
+        if precision == "f32" and self.ch != 64:
+            raise EngineError("FusedTowerEvaluator: the f32 tower exists for 64-channel trunks")
+        self.precision = precision
+        self.in_dtype = torch.float32 if precision == "f32" else torch.bfloat16
         self._buf = {}
         self.kernel_events = None  # bench.py sets this to a list: (start, end) HIP events around the tower kernel alone
         self.refresh()
@@ -81,16 +108,18 @@ class FusedTowerEvaluator:
         m, dev = self.model, self.device
         sl = list(m._shared_layers)
         blocks = sl[3:]
+        f32 = self.precision == "f32"
+        pack3 = _pack3x3_f32 if f32 else _pack3x3
         w, b = _fold(sl[0], sl[1])
-        self.w0 = _pack3x3(w, 16).to(dev)
+        self.w0 = pack3(w, 16).to(dev)
         biases, wl = [b], []
         for blk in blocks:
             for conv, bn in ((blk._conv1, blk._bn1), (blk._conv2, blk._bn2)):
                 w, b = _fold(conv, bn)
-                wl.append(_pack3x3(w, self.ch))
+                wl.append(pack3(w, self.ch))
                 biases.append(b)
         self.n_layers = len(wl)
-        self.wl = (torch.stack(wl) if wl else torch.zeros(1, dtype=torch.bfloat16)).to(dev).contiguous()
+        self.wl = (torch.stack(wl) if wl else torch.zeros(1, dtype=self.in_dtype)).to(dev).contiguous()
         self.bias = torch.stack(biases).to(dev).contiguous()
         pw, pb = _fold(m._policy_head[0], m._policy_head[1])
         vw, vb = _fold(m._value_head[0], m._value_head[1])
@@ -104,9 +133,10 @@ class FusedTowerEvaluator:
         self.kp, self.kv = (n2 + 15) // 16 * 16, (2 * n2 + 15) // 16 * 16
         self.feat_stride = int(self.lib.az_heads_feat_stride(self.board))
         assert self.feat_stride == self.kp + self.kv
-        self.wp = _pack_linear(f(pl.weight), (n2 + 31) // 32 * 32, self.kp).to(dev)
+        packl = _pack_linear_f32 if f32 else _pack_linear
+        self.wp = packl(f(pl.weight), (n2 + 31) // 32 * 32, self.kp).to(dev)
         self.bp = f(pl.bias)
-        self.w1 = _pack_linear(f(v1.weight), 64, self.kv).to(dev)
+        self.w1 = packl(f(v1.weight), 64, self.kv).to(dev)
         self.b1 = f(v1.bias)
         self.w2 = f(v2.weight).reshape(-1)
         self.b2 = float(v2.bias.detach().float().reshape(-1)[0])
@@ -117,8 +147,8 @@ class FusedTowerEvaluator:
         engine; with list + count (after Engine.compact_leaves()) or, when those are None, with the flags, only the slots
         whose leaf needs the network are evaluated (other output rows keep old data)."""
         if x is not None:
-            if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
-                raise EngineError("FusedTowerEvaluator expects a contiguous (B,9,N,N) bf16 batch on the model's GPU")
+            if x.dtype != self.in_dtype or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
+                raise EngineError(f"FusedTowerEvaluator expects a contiguous (B,9,N,N) {self.in_dtype} batch on the model's GPU")
             B = x.shape[0]
             ring_p = leaf_p = list_p = count_p = flags_p = None
         else:
@@ -130,7 +160,7 @@ class FusedTowerEvaluator:
             count_p = C.c_void_p(packed[3]) if len(packed) > 3 and packed[3] else None
             flags_p = C.c_void_p(packed[4]) if len(packed) > 4 and packed[4] else None
         if B not in self._buf:  # zeroed once: the kernels never write the pad columns, and the heads multiply them by zero weights
-            self._buf[B] = (torch.zeros(B, self.feat_stride, dtype=torch.bfloat16, device=self.device),
+            self._buf[B] = (torch.zeros(B, self.feat_stride, dtype=self.in_dtype, device=self.device),
                             torch.empty(B, self.n2, device=self.device), torch.empty(B, device=self.device))
         feat, logits_own, value = self._buf[B]
         logits = logits_out if logits_out is not None else logits_own
@@ -145,16 +175,24 @@ class FusedTowerEvaluator:
         if self.kernel_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        rc = self.lib.az_tower_forward(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
-                                       list_p, count_p, flags_p, P(self.w0), P(self.wl), P(self.bias),
-                                       P(self.headw), P(self.headb), P(feat), self.feat_stride, st)
+        if self.precision == "f32":
+            if list_p is not None:
+                raise EngineError("the f32 tower takes the packed batch with flags (or all slots), not a compact list")
+            rc = self.lib.az_tower_forward_f32(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
+                                               flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.headw), P(self.headb),
+                                               P(feat), self.feat_stride, st)
+        else:
+            rc = self.lib.az_tower_forward(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
+                                           list_p, count_p, flags_p, P(self.w0), P(self.wl), P(self.bias),
+                                           P(self.headw), P(self.headb), P(feat), self.feat_stride, st)
         if rc != 0:
             raise EngineError(f"az_tower_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
         if self.kernel_events is not None:
             ev1.record()
             self.kernel_events.append((ev0, ev1))
-        rc = self.lib.az_heads_forward(self.board, B, P(feat), self.feat_stride, P(self.wp), P(self.bp), P(self.w1), P(self.b1),
-                                       P(self.w2), self.b2, P(logits), P(value), st)
+        heads = self.lib.az_heads_forward_f32 if self.precision == "f32" else self.lib.az_heads_forward
+        rc = heads(self.board, B, P(feat), self.feat_stride, P(self.wp), P(self.bp), P(self.w1), P(self.b1),
+                   P(self.w2), self.b2, P(logits), P(value), st)
         if rc != 0:
             raise EngineError(f"az_heads_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
         value = value.view(B, 1)
@@ -164,6 +202,8 @@ class FusedTowerEvaluator:
         """The same evaluation through az_tower_heads_forward_static: nothing is allocated -- not here (the caller owns
         ``logits`` (B, N*N) and ``values`` (B,) f32) and not in the library (the feature rows between the two kernels live
         in its static per-GPU array).  B is limited to ``az_static_max_boards``; calls on one GPU must not overlap."""
+        if self.precision != "bf16":
+            raise EngineError("forward_static exists for the bf16 tower")
         if x is not None:
             if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
                 raise EngineError("forward_static expects a contiguous (B,9,N,N) bf16 batch on the model's GPU")

@@ -235,6 +235,22 @@ int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16
                      float *logits_dev, float *values_dev, void *stream);
 const char *az_tower_last_error(void);
 
+/* The same two calls at the REFERENCE'S precision: the reference runs its network in float32 (nn_models/base.py:17-19
+ * under core/MCTS_alphazero.py:161-162, no autocast).  f32 operands and f32 accumulation on v_mfma_f32_32x32x2_f32
+ * (each output is a k-ordered fmaf chain; dense peak 157.3 TFLOP/s).  64-channel trunks, board 9 or 15.
+ *   x_f32_dev (n_boards, 9, N, N) f32 or NULL to read the packed leaf batch (with flags_dev, only the flagged slots);
+ *   w0_dev [9 taps][2][2][64][4] f32, wl_dev [n_conv_layers][9][8][2][64][4] f32 ([tap][k-step of 8 ci][k-half][co][4 ci]);
+ *   bias_dev / headw_dev / headb_dev as for az_tower_forward; feat_f32_dev (n_boards, feat_stride) f32 out, same row
+ *   layout and stride rule as az_tower_forward's (zeroed buffer: the pads are never written);
+ *   az_heads_forward_f32: wp_dev [ceil(N*N/32)][KP/8][2][32][4] f32, w1_dev [2][KV/8][2][32][4] f32. */
+int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const float *x_f32_dev,
+                         const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev, const void *w0_dev,
+                         const void *wl_dev, const float *bias_dev, const float *headw_dev, const float *headb_dev, float *feat_f32_dev,
+                         int32_t feat_stride, void *stream);
+int az_heads_forward_f32(int32_t board_size, int32_t n_boards, const float *feat_dev, int32_t feat_stride, const void *wp_dev,
+                         const float *bp_dev, const void *w1_dev, const float *b1_dev, const float *w2_dev, float b2,
+                         float *logits_dev, float *values_dev, void *stream);
+
 /* No counterpart in the reference.  For callers that CANNOT allocate device memory around the evaluation -- code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: az_tower_forward followed by
  * az_heads_forward in one call, with the feature rows that travel between the two kernels kept in a static array

@@ -9,7 +9,7 @@ from .conftest import ROOT
 
 def _declared():
     text = open(os.path.join(ROOT, "include", "az_engine.h")).read()
-    return sorted(set(re.findall(r"\b(az_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(az_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_exported():

@@ -98,7 +98,7 @@ def _tower_callback(ev, shape, dtype):
     return O.EVAL_FN(_cb), calls
 
 
-@pytest.mark.parametrize("precision", ["bf16"])
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
 def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     """engine + tower on the packed/flags path == oracle + the same tower as its evaluator"""
     from alphazero_amd import Engine

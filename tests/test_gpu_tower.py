@@ -50,6 +50,79 @@ def test_fused_tower_matches_fp32_forward(board, blocks, batch, ch):
     assert float((p - ref_p).abs().mean()) <= 1.5 * float((bp.float() - ref_p).abs().mean()) + 1e-4
 
 
+@pytest.mark.parametrize("board,blocks,batch", [(15, 2, 64), (15, 2, 1100), (15, 3, 33), (9, 2, 100), (9, 1, 7), (15, 0, 5), (9, 0, 4),
+                                                (15, 10, 600), (9, 6, 50)])
+def test_f32_tower_matches_fp32_forward(board, blocks, batch):
+    """az_tower_f32.hip: f32 operands, f32 accumulation -- the reference's own arithmetic (nn_models/base.py:17-19).  Bar
+    (north_star: priors within 1e-5 relative): logits within 2e-5 of the logit scale of PyTorch's f32 forward (which differs
+    from any other f32 implementation by summation order and by BatchNorm applied after the conv rather than folded)."""
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(0)
+    net = _randomised(GomokuNet(board, 64, blocks)).eval().cuda()
+    ev = FusedTowerEvaluator(net, "f32")
+    x = torch.randint(-1, 2, (batch, 9, board, board), device="cuda").float()
+    x[:, 8] = torch.where(torch.rand(batch, 1, 1, device="cuda") < 0.5, -1.0, 1.0)
+    torch.backends.cudnn.allow_tf32 = False
+    with torch.inference_mode():
+        ref_p, ref_v = net(x)
+        ref64_p, ref64_v = net.double()(x.double())
+    net.float()
+    p, v = ev(x.contiguous())
+    assert p.shape == ref_p.shape and v.shape == ref_v.shape and p.dtype == torch.float32
+    scale = float(ref_p.abs().max())
+    err = float((p - ref64_p).abs().max())
+    err_torch = float((ref_p - ref64_p).abs().max())
+    assert err <= 2e-5 * scale + 2e-6, (err, scale)
+    assert float((v - ref64_v).abs().max()) <= 2e-5
+    assert err <= 4 * err_torch + 2e-6  # no worse than PyTorch's own f32 forward against an f64 reference
+    # softmax priors within 1e-5 relative of the f64 network's
+    pr, pr64 = torch.softmax(p.double(), 1), torch.softmax(ref64_p, 1)
+    assert float(((pr - pr64).abs() / pr64).max()) <= 1e-5 * max(1.0, scale)
+
+
+def test_f32_tower_packed_leaf_batch_equals_dense_planes():
+    from alphazero_amd import Engine
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(0)
+    for board, G in ((15, 1300), (9, 700)):
+        sims = 10
+        ev = FusedTowerEvaluator(_randomised(GomokuNet(board, 64, 2)).eval().cuda(), "f32")
+        eng = Engine(2, G, sims, board_size=board, nn_dtype=torch.float32, device="cuda:0")
+        nn = eng.new_nn_input()
+        A = board * board
+        logits, values = eng.new(G, A), eng.new(G)
+        it = torch.ones(G, device="cuda")
+        for _ in range(4):
+            eng.begin_search()
+            for _ in range(sims):
+                eng.select_gather(nn)
+                eng.eval_hash(nn, logits, values, 6.0)
+                eng.expand_backup(logits, values, None)
+            eng.play_moves(it, torch.empty(G, A, device="cuda").exponential_(1))
+        eng.begin_search()
+        for _ in range(5):
+            eng.select_gather(nn)
+            eng.eval_hash(nn, logits, values, 6.0)
+            eng.expand_backup(logits, values, None)
+        eng.select_gather(nn)
+        p1, v1 = ev(nn)
+        p1, v1 = p1.clone(), v1.clone()
+        ring, leaf, _, _, flg = eng.leaf_buffers()
+        p2, v2 = ev(None, packed=(ring, leaf), n_boards=G)
+        assert torch.equal(p1, p2) and torch.equal(v1, v2)
+        for t in ev._buf[G]:
+            t.fill_(-1.0)
+        p3, v3 = ev(None, packed=(ring, leaf, None, None, flg), n_boards=G)
+        touched = ev._buf[G][0][:, 0] >= 0
+        assert int(touched.sum()) > 0
+        assert torch.equal(p3[touched], p1[touched]) and torch.equal(v3[touched], v1[touched])
+        eng.check()
+
+
 def test_fused_tower_rejects_other_nets():
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import GomokuNet, TicTacToeNet
