@@ -6,20 +6,24 @@
 Workload (BASELINE.json metric: "MCTS sims/sec + self-play games/sec, gomoku 15x15"; configs[3]):
 gomoku 15x15, 400 simulations per move, 16,384 concurrent games per GPU, the reference's GomokuModel
 (64 ch, 2 residual blocks) with random-init weights (seed 0), synthetic self-play (no dataset needed).
+The PRIMARY line runs the network in float32, the reference's own arithmetic (nn_models/base.py:17-19 under
+core/MCTS_alphazero.py:161-162, no autocast), on the hand-written f32 MFMA tower (az_tower_f32.hip); the same
+workload with the bf16 tower is measured right after it and reported as the object "throughput_mode", with a
+measured decision-agreement figure against the f32 search.
 One STEP = one move of self-play for every game on the GPU: Dirichlet draw, 400 x (select+gather ->
 network forward on the 16,384-position batch -> expand+backup), temperature sampling, game step,
 emission of finished games' (state, pi, z) samples into a pinned host ring, slot recycling.
 So one step = slots x 400 simulations per GPU.  Inputs live in HBM; only finished samples cross PCIe.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel of the step.  With the fused evaluator that is the conv tower (k_tower, MFMA
-                  bound): the convolutions' algorithmic flops for the boards one launch evaluates / mean launch time
-                  (HIP events on the launch stream around the kernel alone), vs 2.5 PFLOP/s dense bf16.  Otherwise the
-                  slower tree kernel (HBM bound).
+  roofline     -- the dominant kernel of the step.  With the fused evaluator that is the conv tower (k_tower_f32 /
+                  k_tower, MFMA bound): the convolutions' algorithmic flops for the boards one launch evaluates / mean
+                  launch time (HIP events on the launch stream around the kernel alone), vs the dense MFMA peak of the
+                  dtype (157.3 TFLOP/s f32, 2.5 PFLOP/s bf16).  Otherwise the slower tree kernel (HBM bound).
   roofline_tree-- the hand-written tree kernel of a simulation step (k_expand_select: backup of simulation i + descent
                   of simulation i+1 in one launch): algorithmic bytes per launch / mean launch time, vs 8 TB/s HBM.
   nn_eval      -- the whole network forward (tower + head linears, or PyTorch/MIOpen with --evaluator model):
-                  achieved TFLOP/s on the boards actually evaluated vs 2.5 PFLOP/s dense bf16.
+                  achieved TFLOP/s on the boards actually evaluated vs the same peak.
   cpu_baseline -- the CPU oracle (oracle/, "port" of the reference path, proven equal to it on the
                   golden fixtures) timed on this box's host cores with the same network on torch-CPU.
 """
@@ -118,38 +122,11 @@ def cpu_baseline(workload: str, budget_s: float = 12.0) -> dict:
 
 
 # ------------------------------------------------------------------------------ GPU bench -------
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="gomoku15", choices=sorted(WORKLOADS))
-    ap.add_argument("--slots", type=int, default=0)
-    ap.add_argument("--sims", type=int, default=0)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--evaluator", default="auto", choices=["auto", "fused", "model", "hash"],
-                    help="fused = hand-written MFMA conv tower (az_tower.hip); model = the module's own PyTorch forward; "
-                         "auto = fused when the network is a GomokuModel-family tower and dtype is bf16")
-    ap.add_argument("--graph", type=int, default=0, help="1: the timed steps replay the simulation step as a captured HIP graph "
-                    "(what the small, launch-bound games want); the per-kernel HIP-event times then come from one eager probe "
-                    "step run after the timed region.  0 (default): eager launches, events inside the timed region")
-    ap.add_argument("--preroll", type=int, default=96, help="cheap 2-sim move rounds that stagger game ages")
-    ap.add_argument("--game-probe", type=int, default=1024, help="games played start to finish (full search, outside the timed "
-                    "region, rank 0) to measure the mean game length that converts plies/s into games/s; 0 = skip")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the "
-                    "barrier / all-reduce / weight-broadcast path on a one-GPU box")
-    args = ap.parse_args()
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    cpu = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.cpu_baseline_seconds > 0:
-        cpu = cpu_baseline(args.workload, args.cpu_baseline_seconds)  # before anything touches the GPU
-
+def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_probe=True):
+    """One timed self-play run of the workload at one network precision -> dict of results (rank 0) / None."""
     import torch
     import torch.distributed as dist
 
@@ -158,19 +135,10 @@ def main():
     from alphazero_amd.engine import copy_to_host
     from alphazero_amd.samples import HostSampleRing, WeightPublisher
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-
     game, n, sims, slots, _ = WORKLOADS[args.workload]
     sims = args.sims or sims
     slots = args.slots or slots
-    tdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    tdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype_name]
     model = make_model(args.workload).to(dev)
     if tdtype != torch.float32:
         model = model.to(tdtype)
@@ -181,12 +149,14 @@ def main():
 
     eng = Engine(game, slots, sims, board_size=n, nn_dtype=tdtype, device=dev)
     d = eng.dims
-    if args.evaluator == "auto":
+    evaluator = args.evaluator
+    if evaluator == "auto":
         from alphazero_amd.fused import FusedTowerEvaluator
 
-        args.evaluator = "fused" if (tdtype == torch.bfloat16 and FusedTowerEvaluator.supports(model)) else "model"
-    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(args.evaluator == "fused"), use_graph=bool(args.graph))
-    if args.evaluator == "hash":  # tree kernels alone (no network)
+        ok = FusedTowerEvaluator.supports(model) and (tdtype == torch.bfloat16 or (tdtype == torch.float32 and WORKLOADS[args.workload][4].get("channels") == 64))
+        evaluator = "fused" if ok else "model"
+    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))
+    if evaluator == "hash":  # tree kernels alone (no network)
         run.evaluate = lambda: eng.eval_hash(run.nn_input, run.logits, run.values, 6.0)
     ring = HostSampleRing(max(4 * slots, 65536), (d.nn_channels, d.height, d.width), d.n_action)
     esize = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}[tdtype]
@@ -280,8 +250,6 @@ def main():
             run.fused.kernel_events = None
         run.evaluate()
         eng.expand_backup(run.logits, run.values, noise)
-        if run.fused is not None:
-            run.fused.kernel_events = None
         run.draw_expo()
         eng.play_moves(inv_tao, run.expo, None, run.actions, run.done)
         return run.done
@@ -293,7 +261,7 @@ def main():
         finalize_pending()  # the previous move's samples -> the host ring, under the search just queued
         collect(done)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(False)
     finalize_pending()
     eng.check()
@@ -304,7 +272,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(True)
     finalize_pending()  # the last move's samples belong to the timed region
     torch.cuda.synchronize()
@@ -332,13 +300,29 @@ def main():
         elapsed = float(tmax[0])
     total_sims, total_games, total_plies = float(tt[1]), float(tt[2]), float(tt[3])
 
+    # what an empty event pair reads on this stream (record -> record): subtracted from every bracketed launch
+    empty = []
+    for _ in range(200):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b.record(); empty.append((a, b))
+    torch.cuda.synchronize()
+    ev_overhead = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
+    tree_ms_raw = sum(a.elapsed_time(b) for a, b in ev_tree) / max(len(ev_tree), 1)
+    nn_ms_raw = sum(a.elapsed_time(b) for a, b in ev_nn) / max(len(ev_nn), 1)
+    tower_ms_raw = sum(a.elapsed_time(b) for a, b in ev_tower) / max(len(ev_tower), 1) if ev_tower else None
+    has_fused = run.fused is not None
+    del run, ring, pending
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+
     # Games per second.  The games that end inside the timed steps were aged by the pre-roll's cheap moves, so their count
     # says nothing about a steady state.  games/s = plies/s (measured above) / mean plies of a game played start to finish
     # with the full search: measured here on a small population, outside the timed region.
     game_len = None
-    if rank == 0 and args.game_probe > 0 and args.evaluator != "hash":
+    if rank == 0 and with_probe and args.game_probe > 0 and evaluator != "hash":
         pe = Engine(game, args.game_probe, sims, board_size=n, nn_dtype=tdtype, device=dev)
-        pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=(args.evaluator == "fused"), use_graph=bool(args.graph))
+        pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))
         pit = torch.full((args.game_probe,), 1.0 / reference_tao(0), device=dev)
         lengths, moves, tp0 = [], 0, time.perf_counter()
         while len(lengths) < args.game_probe and moves <= d.max_plies and time.perf_counter() - tp0 < 60.0:
@@ -351,108 +335,252 @@ def main():
             game_len = {"mean_plies": sum(lengths) / len(lengths), "games": len(lengths), "of": args.game_probe,
                         "seconds": time.perf_counter() - tp0,
                         "how": f"{args.game_probe} games played start to finish with the same network and {sims} sims/move, tao = 1"}
-        del pr, pe
+        del pr
+        pe.close()
+        del pe
 
-    # what an empty event pair reads on this stream (record -> record): subtracted from every bracketed launch
-    empty = []
-    for _ in range(200):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); b.record(); empty.append((a, b))
-    torch.cuda.synchronize()
-    ev_overhead = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
+    if rank != 0:
+        return None
 
+    def corr(ms):
+        return max(ms - ev_overhead, 1e-6)
+
+    peak = PEAK_TFLOPS[dtype_name]
+    nin = d.nn_channels * d.height * d.width
+    launches = sims * (1 if args.graph else steps)  # launches of each per-simulation kernel behind st_probe
+    tree_ms, nn_ms = corr(tree_ms_raw), corr(nn_ms_raw)
+    st = st_probe  # byte counts must come from the same launches the events bracket
+    # algorithmic bytes: child record = Q f64 + {P f32, N i32} + meta u32 = 20 B read by select,
+    # 12 B written at expansion (Q is not stored until the first visit);
+    # leaf batch = packed ring 32*SW B (+ the dense planes only when a PyTorch forward consumes them)
+    planes = 0.0 if has_fused else nin * esize
+    sel_bytes = (20.0 * st["sum_children"] + 4.0 * st["sum_depth"] + st["evals"] * (32.0 * d.state_words + planes)
+                 + st["sims"] * (16.0 + 36.0 * d.state_words + 16.0)) / launches
+    exp_bytes = (st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 12.0 * st["expanded_edges"]
+                 + 32.0 * st["sum_depth"] + 36.0 * st["sims"]) / launches
+    # the tree work of a simulation step is ONE launch: backup of simulation i + descent of simulation i+1
+    dom = ("k_expand_select", sel_bytes + exp_bytes, tree_ms)
+    tower_kernel = "k_tower_f32" if dtype_name == "f32" else "k_tower"
+
+    # HBM traffic from PMC counters cannot be collected inside this run (separate rocprofv3 --pmc passes,
+    # scripts/pmc_traffic.sh); the last committed measurement of this same workload is reported, if present
+    def pmc_traffic(kernel):
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+        if args.workload != "gomoku15" or evaluator != "fused" or not os.path.exists(tpath):
+            return None, None
+        try:
+            t = json.load(open(tpath))[kernel]
+            return (t["FETCH_SIZE"]["corrected_bytes_per_launch"] + t["WRITE_SIZE"]["corrected_bytes_per_launch"],
+                    "bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from separate --pmc passes "
+                    "(scripts/pmc_traffic.sh -> profiles/pmc_traffic_latest.json)")
+        except Exception:
+            return None, None
+
+    traffic, traffic_note = pmc_traffic(dom[0])
+    achieved = dom[1] / (dom[2] * 1e-3) / 1e9 if dom[2] > 0 else 0.0
+    tree_roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": dom[1],
+                     "ms_per_launch": dom[2]}
+    evals_per_launch = st["evals"] / launches  # boards the network really evaluates per simulation step
+    roofline = tree_roofline
+    nn_eval = None
+    if evaluator in ("model", "fused") and hasattr(model, "flops_per_eval"):
+        import torch.nn as tnn
+        conv_flops = sum(2.0 * d.height * d.width * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
+                         for m in model.modules() if isinstance(m, tnn.Conv2d))
+        fl = model.flops_per_eval() * evals_per_launch
+        nn_eval = {"bound": "mfma", "ms_per_batch": nn_ms, "achieved": fl / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
+                   "peak": peak, "unit": "TFLOP/s", "frac": (fl / (nn_ms * 1e-3) / 1e12 / peak) if nn_ms else 0.0,
+                   "flops_per_eval": model.flops_per_eval(), "boards_per_batch": evals_per_launch,
+                   "share_of_step": nn_ms / max(nn_ms + tree_ms, 1e-9),
+                   "implementation": (("az_tower_f32.hip: k_tower_f32 (f32 MFMA conv tower) + k_heads_f32" if dtype_name == "f32" else
+                                       "az_tower.hip: k_tower (fused bf16 MFMA conv tower) + k_heads (MFMA head linears)")
+                                      if evaluator == "fused" else "PyTorch/MIOpen module forward")}
+        if evaluator == "fused" and tower_ms_raw is not None:
+            # the dominant kernel of the step: the fused conv tower (MFMA bound).  Algorithmic flops = the convolutions'
+            # multiply-adds x 2 for the boards this launch evaluates (terminal leaves are skipped, padding is not counted)
+            tw_ms = corr(tower_ms_raw)
+            tw_fl = conv_flops * evals_per_launch
+            ttraffic, tnote = pmc_traffic(tower_kernel)
+            roofline = {"bound": "mfma", "kernel": tower_kernel, "achieved": tw_fl / (tw_ms * 1e-3) / 1e12, "peak": peak,
+                        "unit": "TFLOP/s", "frac": tw_fl / (tw_ms * 1e-3) / 1e12 / peak, "traffic": ttraffic,
+                        "traffic_note": tnote, "flops_per_launch": tw_fl, "boards_per_launch": evals_per_launch,
+                        "ms_per_launch": tw_ms, "share_of_step": tw_ms / max(nn_ms + tree_ms, 1e-9)}
+    out = {
+        "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {sims} sims/move, {slots} concurrent games per GPU, "
+                               f"evaluator={evaluator} ({dtype_name} network arithmetic), one step = one self-play move of every game",
+                   "slots_per_gpu": slots, "sims_per_move": sims, "parallelism": f"games sharded x{world}, no data-path collective"},
+        "plies_per_sec": slots * world * steps / elapsed,
+        "games_per_sec_finished_in_window": total_games / elapsed,
+        "games_per_sec": (slots * world * steps / elapsed / game_len["mean_plies"]) if game_len else None,
+        "games_per_sec_note": "games_per_sec_finished_in_window counts the games that really ended inside the timed steps (aged "
+                              "by the pre-roll); games_per_sec = plies_per_sec / game_length.mean_plies is the steady-state rate",
+        "game_length": game_len,
+        "finished_in_window": {"games": total_games, "mean_plies": (total_plies / total_games) if total_games else None},
+        "roofline": roofline,
+        "roofline_tree": tree_roofline,
+        "tree_kernels": {"k_expand_select": {"ms": tree_ms, "bytes": sel_bytes + exp_bytes,
+                                             "GBps": (sel_bytes + exp_bytes) / max(tree_ms, 1e-9) / 1e6,
+                                             "bytes_descent": sel_bytes, "bytes_expand_backup": exp_bytes},
+                         "event_pair_overhead_ms": ev_overhead,
+                         "timed_with": "probe step after the timed region (timed steps replay a HIP graph)" if args.graph
+                         else "HIP events inside the timed region",
+                         "mean_depth": st["sum_depth"] / max(st["sims"], 1),
+                         "mean_children_per_level": st["sum_children"] / max(st["sum_depth"], 1),
+                         "evals_per_sim": st["evals"] / max(st["sims"], 1)},
+    }
+    if nn_eval is not None:
+        out["nn_eval"] = nn_eval
+    return out
+
+
+def decision_agreement(args, dev, n_pos=1024, plies=12):
+    """How often does the bf16 throughput mode decide like the f32 network?  The same n_pos mid-game positions (reached by
+    `plies` moves of cheap self-play), the same Dirichlet rows, the full search with each precision: fraction of roots
+    whose most-visited move is the same, whose move sampled with the same exponential row is the same, and whose whole
+    visit vector is identical."""
+    import torch
+
+    from alphazero_amd import Engine
+    from alphazero_amd.arena import SelfPlayRunner
+
+    game, n, sims, _, kw = WORKLOADS[args.workload]
+    sims = args.sims or sims
+    if game != 2 or kw.get("channels") != 64:
+        return None
+    torch.manual_seed(99)
+    torch.cuda.manual_seed(99)
+    res, pos_moves = {}, None
+    noise = expo = None
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        model = make_model(args.workload).to(dev).to(dt)
+        eng = Engine(game, n_pos, sims, board_size=n, nn_dtype=dt, device=dev)
+        run = SelfPlayRunner(eng, model, sims, fused=True)
+        A = eng.dims.n_action
+        it = torch.ones(n_pos, device=dev)
+        if pos_moves is None:  # the opening moves, played once (hash evaluator, 8 sims) and replayed for the other precision
+            pos_moves = []
+            lg, vl = eng.new(n_pos, A), eng.new(n_pos)
+            for _ in range(plies):
+                eng.begin_search()
+                for _ in range(8):
+                    eng.select_gather(None)
+                    eng.eval_hash(None, lg, vl, 6.0)
+                    eng.expand_backup(lg, vl, None)
+                a, _ = eng.play_moves(it, torch.empty(n_pos, A, device=dev).exponential_(1))
+                pos_moves.append(a.clone())
+            noise = torch._sample_dirichlet(torch.full((n_pos, A), 0.3, device=dev))
+            expo = torch.empty(n_pos, A, device=dev).exponential_(1)
+        else:
+            lg, vl = eng.new(n_pos, A), eng.new(n_pos)
+            for a in pos_moves:
+                eng.begin_search()
+                eng.select_gather(None)
+                eng.eval_hash(None, lg, vl, 6.0)
+                eng.expand_backup(lg, vl, None)
+                eng.select_gather(None)
+                eng.eval_hash(None, lg, vl, 6.0)
+                eng.expand_backup(lg, vl, None)
+                eng.play_moves(it, torch.ones(n_pos, A, device=dev), a)
+        run.draw_noise = lambda nz=noise, r=run: (r.noise.copy_(nz), r.noise)[1]
+        run.search()
+        visits = eng.new(n_pos, A, dtype=torch.int32)
+        pi = eng.root_policy(visits=visits)
+        eng.check()
+        _, _, active, _ = eng.game_info()
+        res[name] = (visits.clone(), (pi / expo).argmax(1), active.bool().clone())
+        del run
+        eng.close()
+    (v32, s32, a32), (v16, s16, a16) = res["f32"], res["bf16"]
+    live = a32 & a16
+    nl = max(int(live.sum()), 1)
+    return {"positions": nl, "sims_per_move": sims,
+            "same_most_visited_move": float((v32.argmax(1) == v16.argmax(1))[live].sum()) / nl,
+            "same_sampled_move": float((s32 == s16)[live].sum()) / nl,
+            "identical_visit_vectors": float((v32 == v16).all(1)[live].sum()) / nl,
+            "mean_abs_pi_difference": float(((v32.float() - v16.float()).abs().sum(1) / max(sims - 1, 1))[live].mean()) / 2,
+            "how": f"{nl} positions {plies} plies into a game, same Dirichlet and exponential rows, full search with the f32 tower "
+                   "(az_tower_f32.hip) and with the bf16 tower (az_tower.hip); mean_abs_pi_difference = total variation "
+                   "distance between the two root visit distributions"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="gomoku15", choices=sorted(WORKLOADS))
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--sims", type=int, default=0)
+    ap.add_argument("--dtype", default="auto", choices=["auto", "bf16", "f16", "f32"],
+                    help="network arithmetic of the PRIMARY line.  auto = f32, the reference's own precision (nn_models/base.py:17-19), "
+                         "wherever the f32 tower exists (64-channel gomoku nets) or the module's PyTorch forward is used; bf16 for the "
+                         "128-channel config-5 tower")
+    ap.add_argument("--secondary-steps", type=int, default=-1, help="timed steps of the second line at the other precision (bf16 "
+                    "throughput mode beside an f32 primary), reported as the object 'throughput_mode'; -1 = min(steps, 4) at one GPU, 0 = skip")
+    ap.add_argument("--evaluator", default="auto", choices=["auto", "fused", "model", "hash"],
+                    help="fused = hand-written MFMA conv tower (az_tower.hip / az_tower_f32.hip); model = the module's own PyTorch forward; "
+                         "auto = fused when the network is a GomokuModel-family tower the kernels cover")
+    ap.add_argument("--graph", type=int, default=0, help="1: the timed steps replay the simulation step as a captured HIP graph "
+                    "(what the small, launch-bound games want); the per-kernel HIP-event times then come from one eager probe "
+                    "step run after the timed region.  0 (default): eager launches, events inside the timed region")
+    ap.add_argument("--preroll", type=int, default=96, help="cheap 2-sim move rounds that stagger game ages")
+    ap.add_argument("--game-probe", type=int, default=1024, help="games played start to finish (full search, outside the timed "
+                    "region, rank 0) to measure the mean game length that converts plies/s into games/s; 0 = skip")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-agreement", action="store_true", help="skip the f32-vs-bf16 decision-agreement measurement")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the "
+                    "barrier / all-reduce / weight-broadcast path on a one-GPU box")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and args.cpu_baseline_seconds > 0:
+        # before anything touches the GPU (the workers are spawned processes); with several ranks the others wait in the
+        # rendezvous below meanwhile, so the sample is kept short
+        cpu = cpu_baseline(args.workload, args.cpu_baseline_seconds if world == 1 else min(args.cpu_baseline_seconds, 6.0))
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+
+    kw = WORKLOADS[args.workload][4]
+    primary = args.dtype
+    if primary == "auto":
+        primary = "bf16" if (kw.get("channels", 64) != 64 and args.evaluator in ("auto", "fused")) else "f32"
+    out = measure(args, primary, args.steps, args.warmup, dev, rank, world, use_dist)
+    sec_steps = args.secondary_steps if args.secondary_steps >= 0 else (min(args.steps, 4) if world == 1 else 0)
+    second = None
+    if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused"):
+        second = measure(args, "bf16", sec_steps, 1, dev, rank, world, use_dist)
     if rank == 0:
-        def mean_ms(pairs):
-            return max(sum(a.elapsed_time(b) for a, b in pairs) / max(len(pairs), 1) - ev_overhead, 1e-6)
-
-        nin = d.nn_channels * d.height * d.width
-        launches = sims * (1 if args.graph else args.steps)  # launches of each per-simulation kernel behind st_probe
-        tree_ms, nn_ms = mean_ms(ev_tree), mean_ms(ev_nn)
-        st_all, st = st, st_probe  # byte counts must come from the same launches the events bracket
-        # algorithmic bytes: child record = Q f64 + {P f32, N i32} + meta u32 = 20 B read by select,
-        # 12 B written at expansion (Q is not stored until the first visit);
-        # leaf batch = packed ring 32*SW B (+ the dense planes only when a PyTorch forward consumes them)
-        planes = 0.0 if run.fused is not None else nin * esize
-        sel_bytes = (20.0 * st["sum_children"] + 4.0 * st["sum_depth"] + st["evals"] * (32.0 * d.state_words + planes)
-                     + st["sims"] * (16.0 + 36.0 * d.state_words + 16.0)) / launches
-        exp_bytes = (st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 12.0 * st["expanded_edges"]
-                     + 32.0 * st["sum_depth"] + 36.0 * st["sims"]) / launches
-        # the tree work of a simulation step is ONE launch: backup of simulation i + descent of simulation i+1
-        dom = ("k_expand_select", sel_bytes + exp_bytes, tree_ms)
-
-        # HBM traffic from PMC counters cannot be collected inside this run (separate rocprofv3 --pmc passes,
-        # scripts/pmc_traffic.sh); the last committed measurement of this same workload is reported, if present
-        def pmc_traffic(kernel):
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-            if args.workload != "gomoku15" or args.evaluator != "fused" or not os.path.exists(tpath):
-                return None, None
-            try:
-                t = json.load(open(tpath))[kernel]
-                return (t["FETCH_SIZE"]["corrected_bytes_per_launch"] + t["WRITE_SIZE"]["corrected_bytes_per_launch"],
-                        "bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from separate --pmc passes "
-                        "(scripts/pmc_traffic.sh -> profiles/pmc_traffic_latest.json)")
-            except Exception:
-                return None, None
-
-        traffic, traffic_note = pmc_traffic(dom[0])
-        achieved = dom[1] / (dom[2] * 1e-3) / 1e9 if dom[2] > 0 else 0.0
-        tree_roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": dom[1],
-                         "ms_per_launch": dom[2]}
-        evals_per_launch = st["evals"] / launches  # boards the network really evaluates per simulation step
-        roofline = tree_roofline
-        nn_eval = None
-        if args.evaluator in ("model", "fused") and hasattr(model, "flops_per_eval"):
-            import torch.nn as tnn
-            conv_flops = sum(2.0 * d.height * d.width * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
-                             for m in model.modules() if isinstance(m, tnn.Conv2d))
-            fl = model.flops_per_eval() * evals_per_launch
-            nn_eval = {"bound": "mfma", "ms_per_batch": nn_ms, "achieved": fl / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
-                       "peak": 2500.0, "unit": "TFLOP/s", "frac": (fl / (nn_ms * 1e-3) / 1e12 / 2500.0) if nn_ms else 0.0,
-                       "flops_per_eval": model.flops_per_eval(), "boards_per_batch": evals_per_launch,
-                       "share_of_step": nn_ms / max(nn_ms + tree_ms, 1e-9),
-                       "implementation": "az_tower.hip: k_tower (fused bf16 MFMA conv tower) + k_heads (MFMA head linears)" if args.evaluator == "fused"
-                       else "PyTorch/MIOpen module forward"}
-            if args.evaluator == "fused" and ev_tower:
-                # the dominant kernel of the step: the fused conv tower (MFMA bound).  Algorithmic flops = the convolutions'
-                # multiply-adds x 2 for the boards this launch evaluates (terminal leaves are skipped, padding is not counted)
-                tw_ms = mean_ms(ev_tower)
-                tw_fl = conv_flops * evals_per_launch
-                ttraffic, tnote = pmc_traffic("k_tower")
-                roofline = {"bound": "mfma", "kernel": "k_tower", "achieved": tw_fl / (tw_ms * 1e-3) / 1e12, "peak": 2500.0,
-                            "unit": "TFLOP/s", "frac": tw_fl / (tw_ms * 1e-3) / 1e12 / 2500.0, "traffic": ttraffic,
-                            "traffic_note": tnote, "flops_per_launch": tw_fl, "boards_per_launch": evals_per_launch,
-                            "ms_per_launch": tw_ms, "share_of_step": tw_ms / max(nn_ms + tree_ms, 1e-9)}
-        out = {
-            "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {sims} sims/move, {slots} concurrent games per GPU, "
-                                   f"evaluator={args.evaluator}, one step = one self-play move of every game",
-                       "slots_per_gpu": slots, "sims_per_move": sims, "parallelism": f"games sharded x{world}, no data-path collective"},
-            "plies_per_sec": slots * world * args.steps / elapsed,
-            "games_per_sec": (slots * world * args.steps / elapsed / game_len["mean_plies"]) if game_len else None,
-            "games_per_sec_note": "plies_per_sec / game_length.mean_plies (steady state); the games that ended inside the timed "
-                                  "steps had been aged by the pre-roll and are only counted in finished_in_window",
-            "game_length": game_len,
-            "finished_in_window": {"games": total_games, "mean_plies": (total_plies / total_games) if total_games else None},
-            "roofline": roofline,
-            "roofline_tree": tree_roofline,
-            "tree_kernels": {"k_expand_select": {"ms": tree_ms, "bytes": sel_bytes + exp_bytes,
-                                                 "GBps": (sel_bytes + exp_bytes) / max(tree_ms, 1e-9) / 1e6,
-                                                 "bytes_descent": sel_bytes, "bytes_expand_backup": exp_bytes},
-                             "event_pair_overhead_ms": ev_overhead,
-                             "timed_with": "probe step after the timed region (timed steps replay a HIP graph)" if args.graph
-                             else "HIP events inside the timed region",
-                             "mean_depth": st["sum_depth"] / max(st["sims"], 1),
-                             "mean_children_per_level": st["sum_children"] / max(st["sum_depth"], 1),
-                             "evals_per_sim": st["evals"] / max(st["sims"], 1)},
-            "cpu_baseline": cpu,
-        }
-        if nn_eval is not None:
-            out["nn_eval"] = nn_eval
+        out["cpu_baseline"] = cpu
         if cpu:
+            cpu["network_precision"] = "f32 (torch-CPU forward of the same network, as the reference runs it)"
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+        if second is not None:
+            second["note"] = ("the same workload with the bf16 tower (bf16 operands, f32 accumulation): NOT the reference's precision; "
+                              "decisions differ from the f32 search as measured in decision_agreement")
+            if cpu:
+                second["speedup_vs_cpu_baseline_f32_network"] = second["value"] / cpu["value"]
+            if not args.no_agreement:
+                second["decision_agreement"] = decision_agreement(args, dev)
+            out["throughput_mode"] = second
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

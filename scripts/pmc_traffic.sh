@@ -7,9 +7,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --preroll 0 --no-cpu-baseline --game-probe 0 ${BENCH_ARGS:-}"
+ARGS="--steps 1 --warmup 0 --preroll 0 --no-cpu-baseline --no-agreement --game-probe 0 ${BENCH_ARGS:-}"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 300 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "k_select_gather|k_expand_backup|k_expand_select|k_tower" \
+  timeout -s KILL 300 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "k_select_gather|k_expand_backup|k_expand_select|k_tower|k_heads" \
     --output-format csv -d $OUT/$C -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/$C.log 2>&1
   echo "pass $C done"
 done
