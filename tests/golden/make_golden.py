@@ -482,8 +482,52 @@ def make_augment():
     np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
 
 
+# --------------------------------------------------------------------------- learner KATs ---------
+def make_loss():
+    """training/nn_trainer.py:60-94 `Trainer._calculate_loss` and one `Trainer.train()` (:49-58) on a fixed batch with the
+    reference's own model classes: inputs (weights, batch) and outputs (loss, parameters after one SGD step) as data."""
+    from training.nn_trainer import Trainer
+
+    out = {}
+    rng = np.random.default_rng(17)
+
+    def case(tag, model_cls, cin, h, w, A, B, seed):
+        torch.manual_seed(seed)
+        model = model_cls()
+        st = rng.integers(-1, 2, size=(B, cin, h, w)).astype(np.float32)
+        pi = rng.random((B, A)).astype(np.float32)
+        pi /= pi.sum(1, keepdims=True)
+        z = rng.choice([-1.0, 0.0, 1.0], size=(B, 1)).astype(np.float32)
+        batch = (torch.from_numpy(st), torch.from_numpy(pi), torch.from_numpy(z))
+
+        class Pool:
+            def sample(self, n, timeout=None):
+                return batch
+
+        for k, v in model.state_dict().items():
+            out[f"{tag}__w__{k}"] = v.detach().numpy().copy()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        tr = Trainer(model, Pool(), opt, device=torch.device("cpu"))
+        loss = tr._calculate_loss(B)
+        out[f"{tag}__loss"] = np.float32(loss.item())
+        tr.train(B)
+        out[f"{tag}__states"], out[f"{tag}__pis"], out[f"{tag}__z"] = st.astype(np.int8), pi, z
+        for k, v in model.state_dict().items():
+            a = v.detach().numpy().reshape(-1)
+            out[f"{tag}__after_sum__{k}"] = np.float64(a.astype(np.float64).sum())
+            out[f"{tag}__after_head__{k}"] = a[:16].copy()
+        print("loss", tag, float(loss))
+
+    case("tictactoe", TicTacToeModel, 9, 3, 3, 9, 32, 5)
+    case("dab", DotsAndBoxesModel, 25, 4, 4, 24, 32, 6)
+    out["tags"] = np.array(["tictactoe", "dab"])
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "search", "selfplay", "augment"]
+    which = sys.argv[1:] or ["rules", "search", "selfplay", "augment", "loss"]
+    if "loss" in which:
+        make_loss()
     if "rules" in which:
         make_rules()
     if "search" in which:

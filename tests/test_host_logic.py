@@ -320,3 +320,37 @@ def test_learner_reduces_buckets_whose_hooks_did_not_fire(tmp_path):
         assert torch.equal(net.unused.weight, w_unused)  # zero gradient, untouched
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag", ["tictactoe", "dab"])
+def test_learner_loss_and_step_match_reference_golden(tag):
+    """learner.calculate_loss / train_step == the reference's Trainer._calculate_loss / Trainer.train
+    (training/nn_trainer.py:49-94) recorded by tests/golden/make_golden.py on the reference's own model class: same
+    weights (our nets keep its parameter names), same batch -> same loss, same parameters after one SGD step."""
+    import numpy as np
+    import torch
+
+    from alphazero_amd.learner import calculate_loss, train_step
+    from alphazero_amd.nets import DotsAndBoxesNet, TicTacToeNet
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "loss.npz"))
+    net = (TicTacToeNet if tag == "tictactoe" else DotsAndBoxesNet)()
+    pre = f"{tag}__w__"
+    state = {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+    assert set(state) == set(net.state_dict())  # checkpoint interchange: identical names and shapes
+    net.load_state_dict(state)
+    batch = (torch.from_numpy(z[f"{tag}__states"].astype(np.float32)), torch.from_numpy(z[f"{tag}__pis"]),
+             torch.from_numpy(z[f"{tag}__z"]))
+    loss, _, _ = calculate_loss(net, *batch)
+    np.testing.assert_allclose(float(loss), float(z[f"{tag}__loss"]), rtol=1e-6)
+
+    class Pool:
+        def sample(self, n, timeout=None):
+            return batch
+
+    got = train_step(net, torch.optim.SGD(net.parameters(), lr=0.05), Pool(), 32)
+    np.testing.assert_allclose(got[0], float(z[f"{tag}__loss"]), rtol=1e-6)
+    for k, v in net.state_dict().items():
+        a = v.detach().numpy().reshape(-1)
+        np.testing.assert_allclose(a[:16], z[f"{tag}__after_head__{k}"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(a.astype(np.float64).sum(), float(z[f"{tag}__after_sum__{k}"]), rtol=1e-5, atol=1e-5)
