@@ -249,6 +249,11 @@ class ChessArena:
         eng.reset_games(None)
         finished = samples = 0
         put_batch = getattr(experience_pool, "put_batch", None)
+        if put_batch is None:
+            from .samples import SharedRingWriter
+
+            if SharedRingWriter.accepts(experience_pool):  # the reference's shared-memory ring: written in bulk (8x augmented)
+                put_batch = SharedRingWriter(experience_pool, eng).put_batch
         while finished < n_games:
             acts, done = run.move_round(inv_tao)
             done_h = done.cpu()

@@ -295,3 +295,73 @@ def test_gpu_worker_replays_on_the_oracle(oracle):
                            num_simulation=sims, trace=trace)
     tao_of = lambda i: reference_tao(i // slots)
     assert _replay_trace(oracle, trace, pool.items, 1, 3, A, sims, slots, tao_of, 24) == n_games
+
+
+class _RefLikeRing:
+    """The fields and the ``put`` / ``put_tupule_experience`` semantics of utils/share_ring_buffer.py:39-127, restated
+    (the reference itself does not travel to the GPU box); augmentation through oracle/augment.py, which is pinned to
+    the reference's get_enhanced_data by tests/golden/augment.npz."""
+
+    def __init__(self, cap, nn_shape, A, game):
+        import multiprocessing as mp
+
+        self._states = torch.zeros((cap, 1, *nn_shape))
+        self._prior = torch.zeros((cap, 1, A))
+        self._values = torch.zeros((cap, 1))
+        self._write_idx, self._read_idx = mp.Value("i", 0), mp.Value("i", 0)
+        self._size, self._total_written = mp.Value("i", 0), mp.Value("i", 0)
+        self._lock = mp.Lock()
+        self._not_empty = mp.Condition(self._lock)
+        self._capacity, self._game = cap, game
+
+    def put(self, state, prior, value):
+        with self._lock:
+            if self._size.value >= self._capacity:
+                self._read_idx.value = (self._read_idx.value + 1) % self._capacity
+                self._size.value = self._capacity
+            idx = self._write_idx.value
+            self._states[idx].copy_(state)
+            self._prior[idx].copy_(prior)
+            self._values[idx].copy_(value)
+            self._write_idx.value = (idx + 1) % self._capacity
+            self._size.value = min(self._size.value + 1, self._capacity)
+            self._total_written.value += 1
+            self._not_empty.notify()
+
+    def put_tupule_experience(self, exp):
+        from oracle import augment as AUG
+
+        st, pi, z = exp
+        outs, outp, outz = AUG.augment(self._game, st.numpy()[0], pi.numpy()[0], float(z[0]))
+        for t in range(8):
+            self.put(torch.from_numpy(np.ascontiguousarray(outs[t]))[None], torch.from_numpy(np.ascontiguousarray(outp[t]))[None],
+                     torch.tensor([outz[t]]))
+
+
+@pytest.mark.parametrize("name,game,n,A,sims", GAMES)
+def test_bulk_writer_fills_the_reference_ring_like_its_own_puts(name, game, n, A, sims):
+    """self_play_many -> SharedRingWriter (GPU augmentation, one locked bulk write) leaves the reference-style shared
+    ring exactly as the reference's per-sample put_tupule_experience loop would: rows, wrap-around, indices."""
+    from alphazero_amd.arena import ChessArena
+
+    torch.manual_seed(5)
+    arena = ChessArena(functools.partial(HashNet, A, 5.0), _game_cls(name), torch.device("cuda:0"), n_slots=8, num_simulation=sims)
+    d = arena._engine(8).dims
+    shape = (d.nn_channels, d.height, d.width)
+    listed = ListPool()
+    trace = []
+    torch.manual_seed(6)
+    torch.cuda.manual_seed(6)
+    arena.self_play_many(20, 1.0, listed, trace=trace)  # the per-sample path: what the samples are
+    cap = 8 * len(listed.items) - 37  # smaller than the data: wraps and overwrites
+    want = _RefLikeRing(cap, shape, A, game)
+    for exp in listed.items:
+        want.put_tupule_experience(exp)
+    got = _RefLikeRing(cap, shape, A, game)
+    torch.manual_seed(6)
+    torch.cuda.manual_seed(6)
+    arena.games_played = 0
+    arena.self_play_many(20, 1.0, got)  # same seeds => same games, through the bulk writer
+    for f in ("_write_idx", "_read_idx", "_size", "_total_written"):
+        assert getattr(got, f).value == getattr(want, f).value, f
+    assert torch.equal(got._states, want._states) and torch.equal(got._prior, want._prior) and torch.equal(got._values, want._values)
