@@ -67,8 +67,9 @@ class SelfPlayRunner:
         G, A = engine.n_slots, engine.dims.n_action
         dev = engine.device
         self.nn_input = engine.new_nn_input()
-        self.logits = torch.empty(G, A, device=dev)
-        self.values = torch.empty(G, device=dev)
+        R = engine.rows  # G x leaves per step: rows of the network batch
+        self.logits = torch.empty(R, A, device=dev)
+        self.values = torch.empty(R, device=dev)
         self.noise = torch.empty(G, A, device=dev)
         self.expo = torch.empty(G, A, device=dev)
         self.actions = torch.empty(G, dtype=torch.int32, device=dev)
@@ -94,7 +95,7 @@ class SelfPlayRunner:
     # one model forward on the gathered batch -> self.logits / self.values (f32, engine device)
     def evaluate(self) -> None:
         if self.fused is not None:
-            _, v = self.fused(None, logits_out=self.logits, packed=self._packed, n_boards=self.e.n_slots)
+            _, v = self.fused(None, logits_out=self.logits, packed=self._packed, n_boards=self.e.rows)
             self.values = v.view(-1)  # handed to expand_backup as is (no copy)
             return
         x = self.nn_input
@@ -159,6 +160,8 @@ class SelfPlayRunner:
         num_sims - 1 x (network, backup + next descent), then the last network evaluation and backup"""
         noise = self.draw_noise()
         e = self.e
+        if e.leaves_per_step > 1:
+            return self._search_waves(noise)
         if self.use_graph and (self._graph is None or self._graph_noise != (noise is not None)):
             self._capture(noise)
         e.begin_search()
@@ -170,6 +173,24 @@ class SelfPlayRunner:
                 self.eval_step(noise)
         self.evaluate()
         e.expand_backup(self.logits, self.values, noise)
+
+    def _search_waves(self, noise) -> None:
+        """the search with virtual loss / in-tree leaf batching (engine created with leaves_per_step K > 1): every step
+        evaluates up to K leaves per tree in one network batch.  A tree whose descents collide on a pending leaf queues
+        fewer than K, so the number of steps is not known in advance: run the fewest that could suffice, then ask the
+        engine how many simulations the slowest tree still needs (one host sync per round) and go on."""
+        e, K = self.e, self.e.leaves_per_step
+        nn_in = None if self.fused is not None else self.nn_input
+        e.begin_search()
+        left = self.num_sims
+        self.wave_steps = 0
+        while left > 0:
+            for _ in range((left + K - 1) // K):
+                e.select_wave(self.num_sims, nn_in)
+                self.evaluate()
+                e.expand_wave(self.logits, self.values, noise)
+                self.wave_steps += 1
+            _, left = e.search_remaining(self.num_sims)
 
     def move_round(self, inv_tao: torch.Tensor, forced: Optional[torch.Tensor] = None):
         """search + temperature sampling + step, for every active slot (training/self_play.py:36-83)"""

@@ -45,11 +45,16 @@
 namespace az {
 
 enum : int { KIND_EVAL = 0, KIND_TERMINAL = 1 };
+constexpr int WAVE_KMAX = 16;  // most leaves per tree per step
 enum : int { ERR_EDGE_CAP = 1, ERR_NODE_CAP = 2, ERR_DEPTH_CAP = 4, ERR_ILLEGAL = 8, ERR_NO_ROOT = 16, ERR_EMIT_SETPOS = 32 };
 
 struct View {  // kernel argument: raw device pointers + sizes
   int G, E, D;
+  int K;        // leaves per tree per step (1 = the reference's sequential search); per-simulation arrays hold G*K rows
   float c_puct, epsilon;
+  double vl;    // VIRTUAL_LOSS (config/basic.py:25), used by the wave kernels only
+  int32_t *waveCnt;              // [G] leaves queued by the last k_select_wave
+  unsigned long long *remain;    // [2] {sum, max} of simulations left (az_search_remaining)
   double *edgeQ;
   int2 *edgePN;
   uint32_t *edgeMeta;
@@ -356,29 +361,33 @@ __global__ __launch_bounds__(1024) void k_compact_leaves(View v, int per) {
 // MCTS._get_prior :180-192, MCTSNode.expand :43-57, MCTSNode.update :80-88, MCTS._bacaward :194-200.
 // PRE: also prepare the NEXT descent of the same slot (k_expand_select): its slot words ride with this body's first batch
 // (edge count and root visits are handed over as this body leaves them), its ring words with the second.
+// Wave mode (k_expand_wave): the leaves of one tree are expanded one after the other by the same wavefront; `vs` is the
+// leaf's row in the per-simulation arrays (g * K + j), and the tree's edge count / root statistics travel in registers.
+struct WaveCarry { int used, rootN; double rootQ; };
+
 template <class GT, bool PRE>
 __device__ __forceinline__ void expand_backup_body(const View &v, const float *logits, const float *values, const float *noise,
-                                                   const int g, const int lane, SelPre<GT> *sp) {
+                                                   const int g, const int lane, SelPre<GT> *sp, const int vs, WaveCarry *wc) {
   const bool slotActive = v.active[g] != 0;  // tested after the batch below is on its way (all of it is valid memory)
   __shared__ uint32_t st[GT::SW];
   constexpr int A = GT::A, NI = (A + 63) / 64;
   const size_t eb = (size_t)g * v.E;
-  const int32_t *path = v.path + (size_t)g * v.D;
+  const int32_t *path = v.path + (size_t)vs * v.D;
   // Everything that depends only on the slot is requested up front, in one batch (one memory round trip): the leaf
   // record, the leaf board, the network's row, the root statistics and the first 64 path entries (entries past the
   // leaf's depth are stale and ignored).  The second batch is the path's child records; then come the stores.
-  const int4 lf = v.leaf[g];
-  const uint32_t bw = lane < GT::SW ? v.leafRing[((size_t)g * 8 + 7) * GT::SW + lane] : 0u;
+  const int4 lf = v.leaf[vs];
+  const uint32_t bw = lane < GT::SW ? v.leafRing[((size_t)vs * 8 + 7) * GT::SW + lane] : 0u;
   float p[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int a = lane + 64 * i;
-    p[i] = logits[(size_t)g * A + min(a, A - 1)];
+    p[i] = logits[(size_t)vs * A + min(a, A - 1)];
   }
-  const float nnv = values[g];
-  const int used = v.edgeCnt[g];
-  const int rootN = v.rootN[g];
-  const double rootQ = v.rootQ[g];
+  const float nnv = values[vs];
+  const int used = wc ? wc->used : v.edgeCnt[g];
+  const int rootN = wc ? wc->rootN : v.rootN[g];
+  const double rootQ = wc ? wc->rootQ : v.rootQ[g];
   const int pth = lane < v.D ? path[lane] : 0;
   if (PRE) {
     sp->active = slotActive;
@@ -458,6 +467,7 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
       off += __popcll(bal[i]);
     }
     if (PRE) sp->used = used + nLegal;
+    if (wc) wc->used = used + nLegal;
     if (lane == 0) {
       v.edgeCnt[g] = used + nLegal;
       // the leaf's own edge is path[depth-1] = lane 0's path edge: link it to its new block
@@ -503,17 +513,197 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
     if (__popcll(fm) & 1) val = -val;
   }
   if (PRE) sp->rootN = rootN + 1;
+  const double newRootQ = rootQ + (val - rootQ) / (double)(rootN + 1);
+  if (wc) { wc->rootN = rootN + 1; wc->rootQ = newRootQ; }
   if (lane == 0) {
-    const int n = rootN + 1;
-    v.rootN[g] = n;
-    v.rootQ[g] = rootQ + (val - rootQ) / (double)n;
+    v.rootN[g] = rootN + 1;
+    v.rootQ[g] = newRootQ;
   }
 }
 
 template <class GT>
 __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logits, const float *values,
                                                       const float *noise) {
-  expand_backup_body<GT, false>(v, logits, values, noise, blockIdx.x, threadIdx.x, nullptr);
+  expand_backup_body<GT, false>(v, logits, values, noise, blockIdx.x, threadIdx.x, nullptr, blockIdx.x, nullptr);
+}
+
+// ------------------------------------------------------------------------- wave search --------
+// Virtual loss and in-tree leaf batching.  The reference carries the hooks -- MCTSNode.pending / .virtual_loss
+// (core/MCTS_alphazero.py:32-33), `q - child.virtual_loss / (child.visits + 1)` in select (:70), USE_VIRTUAL_LOSS /
+// VIRTUAL_LOSS / INFER_BATCH_SIZE (config/basic.py:19-30) -- and no code that sets them; the rule implemented here (and
+// restated in oracle/az_oracle.c, az_oracle_search_wave) is: a step makes up to min(K, simulations left) descents of a
+// tree, one after the other, a child's virtual loss being VIRTUAL_LOSS x (descents already queued in this step that pass
+// through it); tree statistics do not change inside a step; a descent that ends on a leaf already queued closes the
+// step and is dropped; the queued leaves are evaluated as rows g*K .. g*K+count-1 of ONE network batch and then expanded
+// and backed up in queue order.  K = 1 is the sequential search, bit for bit.
+template <class GT, typename OutT>
+__global__ __launch_bounds__(64) void k_select_wave(View v, OutT *nn_input, int target) {
+  constexpr int DL = GT::PMAX + 1, NI = (GT::A + 63) / 64, RW = SelPre<GT>::RW;
+  __shared__ uint32_t hist[8][GT::SW];
+  __shared__ uint32_t cur[GT::SW];
+  __shared__ int32_t wp[WAVE_KMAX][DL];  // the queued descents' paths: edge followed at each level
+  __shared__ int32_t wlen[WAVE_KMAX];
+  const int g = blockIdx.x, lane = threadIdx.x, K = v.K;
+  SelPre<GT> s;
+  s.active = v.active[g] != 0;
+  s.ply = v.ply[g];
+  s.player = v.player[g];
+  s.used = v.edgeCnt[g];
+  s.rootN = v.rootN[g];
+  sel_load_ring<GT>(v, g, lane, s);
+  if (lane < K) v.evalFlag[(size_t)g * K + lane] = 0;
+  const int budget = s.active ? min(K, target - s.rootN) : 0;
+  if (budget <= 0) { if (lane == 0) v.waveCnt[g] = 0; return; }
+  const int ply = s.ply, used = s.used;
+  const size_t eb = (size_t)g * v.E;
+  double eq[NI];
+  int2 epn[NI];
+  uint32_t em[NI];
+  auto fetch = [&](int base, int cnt) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int i = min(lane + 64 * k, cnt - 1);
+      const size_t e = eb + base + i;
+      eq[k] = v.edgeQ[e];
+      epn[k] = v.edgePN[e];
+      em[k] = v.edgeMeta[e];
+    }
+  };
+  int nq = 0;
+  unsigned long long scanned = 0, sumDepth = 0;
+  int nEval = 0, nTerm = 0;
+  for (int j = 0; j < budget; ++j) {
+    __syncthreads();  // the previous descent is done with hist / cur
+    if (used > 0) fetch(0, GT::PMAX - ply);
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const int i = lane + 64 * k;
+      if (i < 8 * GT::SW) hist[i / GT::SW][i % GT::SW] = s.rw[k];
+    }
+    if (lane < GT::SW) cur[lane] = s.cw;
+    __syncthreads();
+    uint32_t share = (1u << nq) - 1u;  // queued descents that followed the same edges so far
+    int head = 0, depth = 0, kind = KIND_EVAL, base = 0, pl = s.player, nParent = s.rootN;
+    float tval = 0.0f;
+    if (used > 0) {
+      for (;;) {
+        if (depth >= v.D || depth >= DL) { if (lane == 0) atomicOr(v.err, ERR_DEPTH_CAP); return; }
+        const int cnt = GT::PMAX - (ply + depth);
+        const float sqrtN = (float)sqrt((double)nParent);
+        float best = -INFINITY;
+        int bestIdx = 0x7fffffff, bestN = 0;
+        uint32_t bestMeta = 0;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+          const int i = lane + 64 * k;
+          int c = 0;  // queued descents through this child
+          for (uint32_t m = share; m; m &= m - 1u) {
+            const int p = __ffs((int)m) - 1;
+            c += (wlen[p] > depth && wp[p][depth] == base + i) ? 1 : 0;
+          }
+          const double q0 = epn[k].y > 0 ? eq[k] : 0.0;
+          double qs = (em[k] & META_SAME) ? q0 : -q0;
+          qs = qs - (v.vl * (double)c) / (double)(epn[k].y + 1);  // core/MCTS_alphazero.py:70
+          const float u = ((v.c_puct * __int_as_float(epn[k].x)) * sqrtN) / (float)(epn[k].y + 1);
+          const float sc = (float)qs + u;
+          if (i < cnt && sc > best) { best = sc; bestIdx = i; bestMeta = em[k]; bestN = epn[k].y; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const float ob = __shfl_xor(best, off, 64);
+          const int oi = __shfl_xor(bestIdx, off, 64);
+          const uint32_t om = (uint32_t)__shfl_xor((int)bestMeta, off, 64);
+          const int on = __shfl_xor(bestN, off, 64);
+          if (ob > best || (ob == best && oi < bestIdx)) { best = ob; bestIdx = oi; bestMeta = om; bestN = on; }
+        }
+        bestIdx = uni(bestIdx);
+        const uint32_t meta = (uint32_t)uni((int)bestMeta);
+        const int nEdge = uni(bestN);
+        scanned += (unsigned)cnt;
+        if (bestIdx >= cnt) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
+        const int a = (int)(meta & META_ACT);
+        const int kid = (int)(meta >> META_KID_SHIFT);
+        if (kid) fetch(kid - 1, cnt - 1);
+        const int edge = base + bestIdx;
+        uint32_t ns = 0;
+        for (uint32_t m = share; m; m &= m - 1u) {
+          const int p = __ffs((int)m) - 1;
+          if (wlen[p] > depth && wp[p][depth] == edge) ns |= 1u << p;
+        }
+        share = ns;
+        if (lane == 0) wp[nq][depth] = edge;
+        ++depth;
+        const int mover = pl;
+        pl = GT::apply(cur, a, mover, lane);
+        if (lane < GT::SW) hist[head][lane] = cur[lane];
+        head = (head + 1) & 7;
+        __syncthreads();
+        if (kid) { base = kid - 1; nParent = nEdge; continue; }
+        const int term = uni(GT::terminal(cur, a, mover, ply + depth, lane));
+        if (term != T_NONE) { kind = KIND_TERMINAL; tval = terminal_value(term, pl); }
+        break;
+      }
+    }
+    bool dup = false;  // the leaf reached is already queued <=> a queued descent shares the whole path and ends here
+    for (uint32_t m = share; m; m &= m - 1u) dup |= wlen[__ffs((int)m) - 1] == depth;
+    if (dup) break;
+    const size_t vs = (size_t)g * K + nq;
+    if (lane == 0) {
+      wlen[nq] = depth;
+      v.leaf[vs] = make_int4(depth, kind, (int)__float_as_uint(tval), pl);
+      v.evalFlag[vs] = kind == KIND_EVAL;
+    }
+    for (int l = lane; l < depth; l += 64) v.path[vs * v.D + l] = wp[nq][l];
+    if (kind == KIND_EVAL) {
+      uint32_t *lr = v.leafRing + vs * 8 * GT::SW;
+      for (int i = lane; i < 8 * GT::SW; i += 64) lr[i] = hist[(head + i / GT::SW) & 7][i % GT::SW];
+      if (nn_input) write_planes<GT, OutT>(hist, head, pl, nn_input + vs * (GT::CIN * GT::HW), lane);
+      ++nEval;
+    } else {
+      ++nTerm;
+    }
+    sumDepth += (unsigned)depth;
+    ++nq;
+  }
+  if (lane == 0) {
+    v.waveCnt[g] = nq;
+    unsigned long long *st = v.stat + (size_t)g * 6;
+    st[0] += (unsigned)nq; st[1] += sumDepth; st[2] += scanned; st[3] += (unsigned)nEval; st[4] += (unsigned)nTerm;
+  }
+}
+
+template <class GT>
+__global__ __launch_bounds__(64) void k_expand_wave(View v, const float *logits, const float *values, const float *noise) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const int cnt = v.waveCnt[g];
+  WaveCarry wc{v.edgeCnt[g], v.rootN[g], v.rootQ[g]};
+  if (!v.active[g] || cnt <= 0) return;
+  for (int j = 0; j < cnt; ++j) {
+    expand_backup_body<GT, false>(v, logits, values, noise, g, lane, nullptr, g * v.K + j, &wc);
+    __syncthreads();  // the next leaf's path may share edges this one has just updated; `st` is reused
+  }
+  if (lane == 0) v.waveCnt[g] = 0;
+}
+
+// simulations still to run for a search of `target` simulations: {sum over active trees, max} (az_search_remaining)
+__global__ __launch_bounds__(256) void k_search_remaining(View v, int target) {
+  __shared__ unsigned long long ssum[256];
+  __shared__ int smax[256];
+  const int t = threadIdx.x;
+  unsigned long long sum = 0;
+  int mx = 0;
+  for (int g = blockIdx.x * 256 + t; g < v.G; g += gridDim.x * 256) {
+    const int r = v.active[g] ? max(target - v.rootN[g], 0) : 0;
+    sum += (unsigned)r;
+    mx = max(mx, r);
+  }
+  ssum[t] = sum; smax[t] = mx;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (t < off) { ssum[t] += ssum[t + off]; smax[t] = max(smax[t], smax[t + off]); }
+    __syncthreads();
+  }
+  if (t == 0) { atomicAdd(&v.remain[0], ssum[0]); atomicMax(&v.remain[1], (unsigned long long)smax[0]); }
 }
 
 // The end of simulation i and the beginning of simulation i+1 of the same tree in one launch (the search loop
@@ -524,7 +714,7 @@ template <class GT, typename OutT>
 __global__ __launch_bounds__(64) void k_expand_select(View v, const float *logits, const float *values, const float *noise,
                                                       OutT *nn_input) {
   SelPre<GT> s;
-  expand_backup_body<GT, true>(v, logits, values, noise, blockIdx.x, threadIdx.x, &s);
+  expand_backup_body<GT, true>(v, logits, values, noise, blockIdx.x, threadIdx.x, &s, blockIdx.x, nullptr);
   __syncthreads();
   select_gather_body<GT, OutT>(v, nn_input, blockIdx.x, threadIdx.x, s);
 }
@@ -736,6 +926,7 @@ __global__ void k_reset_games(View v, const uint8_t *mask) {
   v.edgeCnt[g] = 0;
   v.rootN[g] = 0;
   v.rootQ[g] = 0.0;
+  v.waveCnt[g] = 0;
 }
 
 __global__ void k_begin_search(View v) {
@@ -744,6 +935,7 @@ __global__ void k_begin_search(View v) {
   v.edgeCnt[g] = 0;
   v.rootN[g] = 0;
   v.rootQ[g] = 0.0;
+  v.waveCnt[g] = 0;
 }
 
 __global__ void k_game_info(View v, int32_t *plies, int32_t *player, uint8_t *active, float *result) {
@@ -890,6 +1082,7 @@ int az_create(const az_config *cfg, az_engine **out) {
     g_create_err = "n_slots >= 1 and 1 <= max_sims <= 65535 required"; return AZ_EINVAL;
   }
   if (cfg->nn_dtype < AZ_NN_F32 || cfg->nn_dtype > AZ_NN_F16) { g_create_err = "bad nn_dtype"; return AZ_EINVAL; }
+  if (cfg->leaves_per_step < 0 || cfg->leaves_per_step > WAVE_KMAX) { g_create_err = "leaves_per_step must be 0 .. 16"; return AZ_EINVAL; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev) {
     g_create_err = "no usable HIP device (this library has no CPU path)"; return AZ_EHIP;
@@ -919,8 +1112,11 @@ int az_create(const az_config *cfg, az_engine **out) {
   View &v = e->v;
   memset(&v, 0, sizeof(v));
   v.G = d.n_slots; v.E = d.edge_cap; v.D = d.depth_cap;
+  v.K = cfg->leaves_per_step > 1 ? cfg->leaves_per_step : 1;
+  v.vl = 0.3;  // VIRTUAL_LOSS, config/basic.py:25 (az_set_virtual_loss)
+  d.leaves_per_step = v.K;
   v.c_puct = cfg->c_puct; v.epsilon = cfg->epsilon;
-  const size_t G = (size_t)d.n_slots, E = (size_t)d.edge_cap;
+  const size_t G = (size_t)d.n_slots, E = (size_t)d.edge_cap, GK = G * (size_t)v.K;  // GK: rows of the per-simulation arrays
   int64_t total = 0;
   bool ok = true;
   auto alloc = [&](size_t bytes) -> void * {
@@ -937,12 +1133,14 @@ int az_create(const az_config *cfg, az_engine **out) {
   v.edgeCnt = (int32_t *)alloc(G * sizeof(int32_t));
   v.rootN = (int32_t *)alloc(G * sizeof(int32_t));
   v.rootQ = (double *)alloc(G * sizeof(double));
-  v.path = (int32_t *)alloc(G * (size_t)d.depth_cap * sizeof(int32_t));
-  v.leaf = (int4 *)alloc(G * sizeof(int4));
-  v.leafRing = (uint32_t *)alloc(G * 8 * (size_t)d.state_words * sizeof(uint32_t));
+  v.path = (int32_t *)alloc(GK * (size_t)d.depth_cap * sizeof(int32_t));
+  v.leaf = (int4 *)alloc(GK * sizeof(int4));
+  v.leafRing = (uint32_t *)alloc(GK * 8 * (size_t)d.state_words * sizeof(uint32_t));
   v.evalCount = (int32_t *)alloc(64);
-  v.evalList = (int32_t *)alloc(G * sizeof(int32_t));
-  const size_t flag_bytes = (size_t)((d.n_slots + 16383) / 16384) * 16384;  // 1024 threads x a multiple of 16 flags
+  v.evalList = (int32_t *)alloc(GK * sizeof(int32_t));
+  v.waveCnt = (int32_t *)alloc(G * sizeof(int32_t));
+  v.remain = (unsigned long long *)alloc(2 * sizeof(unsigned long long));
+  const size_t flag_bytes = (size_t)((GK + 16383) / 16384) * 16384;  // 1024 threads x a multiple of 16 flags
   v.evalFlag = (uint8_t *)alloc(flag_bytes);
   v.traj = (uint32_t *)alloc(G * (size_t)(d.max_plies + 1) * d.state_words * sizeof(uint32_t));
   v.trajPlayer = (int8_t *)alloc(G * (size_t)(d.max_plies + 1));
@@ -964,7 +1162,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   // small state starts defined; the big pools need no clearing (bump allocated, written before read)
   if (hipMemset(v.stat, 0, G * 6 * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(v.err, 0, sizeof(int32_t)) != hipSuccess || hipMemset(v.evalCount, 0, 64) != hipSuccess || hipMemset(v.evalFlag, 0, flag_bytes) != hipSuccess || hipMemset(v.active, 0, G) != hipSuccess ||
-      hipMemset(v.ply, 0, G * sizeof(int32_t)) != hipSuccess || hipMemset(v.leaf, 0, G * sizeof(int4)) != hipSuccess ||
+      hipMemset(v.ply, 0, G * sizeof(int32_t)) != hipSuccess || hipMemset(v.leaf, 0, GK * sizeof(int4)) != hipSuccess || hipMemset(v.waveCnt, 0, G * sizeof(int32_t)) != hipSuccess ||
       hipMemset(v.trajPlayer, 0, G * (size_t)(d.max_plies + 1)) != hipSuccess) {
     g_create_err = "hipMemset failed";
     for (void *p : e->allocs) (void)hipFree(p);
@@ -1088,6 +1286,7 @@ int az_leaf_buffers(const az_engine *e, const void **ring_dev, const void **leaf
 
 int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
   if (!e) return AZ_EINVAL;
+  if (e->v.K > 1) { e->err = "engine created with leaves_per_step > 1: use az_select_wave / az_expand_wave"; return AZ_EINVAL; }
   DeviceGuard guard(e->cfg.device);
   const dim3 grid(e->v.G), block(64);
   hipStream_t s = (hipStream_t)stream;
@@ -1102,12 +1301,13 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
 int az_compact_leaves(az_engine *e, void *stream) {
   if (!e) return AZ_EINVAL;
   DeviceGuard guard(e->cfg.device);
-  hipLaunchKernelGGL(k_compact_leaves, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->v, ((e->v.G + 16383) / 16384) * 16);
+  hipLaunchKernelGGL(k_compact_leaves, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->v, ((e->v.G * e->v.K + 16383) / 16384) * 16);
   return launch_check(e, "k_compact_leaves");
 }
 
 int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev, void *stream) {
   if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
+  if (e->v.K > 1) { e->err = "engine created with leaves_per_step > 1: use az_select_wave / az_expand_wave"; return AZ_EINVAL; }
   DeviceGuard guard(e->cfg.device);
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_backup<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, logits_dev, values_dev, noise_dev));
   return launch_check(e, "k_expand_backup");
@@ -1116,6 +1316,7 @@ int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_
 int az_expand_select(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev, void *nn_input_dev,
                      void *stream) {
   if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
+  if (e->v.K > 1) { e->err = "engine created with leaves_per_step > 1: use az_select_wave / az_expand_wave"; return AZ_EINVAL; }
   DeviceGuard guard(e->cfg.device);
   const dim3 grid(e->v.G), block(64);
   hipStream_t s = (hipStream_t)stream;
@@ -1125,6 +1326,49 @@ int az_expand_select(az_engine *e, const float *logits_dev, const float *values_
     default: AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_select<GT, f16_t>), grid, block, 0, s, e->v, logits_dev, values_dev, noise_dev, (f16_t *)nn_input_dev)); break;
   }
   return launch_check(e, "k_expand_select");
+}
+
+int az_select_wave(az_engine *e, void *nn_input_dev, int32_t sims_target, void *stream) {
+  if (!e || sims_target < 1) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
+  if (sims_target > e->cfg.max_sims) { e->err = "sims_target exceeds max_sims"; return AZ_EINVAL; }
+  const dim3 grid(e->v.G), block(64);
+  hipStream_t s = (hipStream_t)stream;
+  switch (e->cfg.nn_dtype) {
+    case AZ_NN_F32: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_wave<GT, float>), grid, block, 0, s, e->v, (float *)nn_input_dev, (int)sims_target)); break;
+    case AZ_NN_BF16: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_wave<GT, bf16_t>), grid, block, 0, s, e->v, (bf16_t *)nn_input_dev, (int)sims_target)); break;
+    default: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_wave<GT, f16_t>), grid, block, 0, s, e->v, (f16_t *)nn_input_dev, (int)sims_target)); break;
+  }
+  return launch_check(e, "k_select_wave");
+}
+
+int az_expand_wave(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev, void *stream) {
+  if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_wave<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, logits_dev, values_dev, noise_dev));
+  return launch_check(e, "k_expand_wave");
+}
+
+int az_search_remaining(az_engine *e, int32_t sims_target, int64_t *sum_out, int32_t *max_out, void *stream) {
+  if (!e || sims_target < 1) return AZ_EINVAL;
+  DeviceGuard guard(e->cfg.device);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long h[2] = {0, 0};
+  AZ_HIP(hipMemsetAsync(e->v.remain, 0, sizeof(h), s));
+  const int blocks = (e->v.G + 255) / 256 < 64 ? (e->v.G + 255) / 256 : 64;
+  hipLaunchKernelGGL(k_search_remaining, dim3(blocks), dim3(256), 0, s, e->v, (int)sims_target);
+  AZ_HIP(hipMemcpyAsync(h, e->v.remain, sizeof(h), hipMemcpyDeviceToHost, s));
+  AZ_HIP(hipStreamSynchronize(s));
+  if (sum_out) *sum_out = (int64_t)h[0];
+  if (max_out) *max_out = (int32_t)h[1];
+  return AZ_OK;
+}
+
+int az_set_virtual_loss(az_engine *e, double virtual_loss) {
+  if (!e) return AZ_EINVAL;
+  if (!(virtual_loss > 0.0)) { e->err = "VIRTUAL_LOSS must be > 0 (config/basic.py:46-47)"; return AZ_EINVAL; }
+  e->v.vl = virtual_loss;
+  return AZ_OK;
 }
 
 int az_root_policy(az_engine *e, float *pi_dev, int32_t *visits_dev, double *child_q_dev, float *root_prior_dev, void *stream) {
@@ -1259,7 +1503,7 @@ int az_reset_stats(az_engine *e, void *stream) {
 int az_eval_hash(az_engine *e, const void *nn_input_dev, float scale, float *logits_dev, float *values_dev, void *stream) {
   if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
   DeviceGuard guard(e->cfg.device);
-  const dim3 grid(e->v.G), block(64);
+  const dim3 grid(e->v.G * e->v.K), block(64);  // one row per (slot, leaf of the step)
   hipStream_t s = (hipStream_t)stream;
   const int A = e->dims.n_action;
   if (!nn_input_dev) {  // read the packed leaf batch of the last descent

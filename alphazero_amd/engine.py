@@ -22,14 +22,14 @@ _NN_DTYPES = {torch.float32: NN_F32, torch.bfloat16: NN_BF16, torch.float16: NN_
 class AzConfig(C.Structure):
     _fields_ = [("game", C.c_int32), ("board_size", C.c_int32), ("n_slots", C.c_int32), ("max_sims", C.c_int32),
                 ("c_puct", C.c_float), ("epsilon", C.c_float), ("nn_dtype", C.c_int32), ("device", C.c_int32),
-                ("edge_cap", C.c_int32), ("reserved", C.c_int32)]
+                ("edge_cap", C.c_int32), ("leaves_per_step", C.c_int32)]
 
 
 class AzDims(C.Structure):
     _fields_ = [("n_action", C.c_int32), ("state_channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
                 ("nn_channels", C.c_int32), ("max_plies", C.c_int32), ("state_words", C.c_int32),
                 ("edge_cap", C.c_int32), ("node_cap", C.c_int32), ("depth_cap", C.c_int32), ("n_slots", C.c_int32),
-                ("reserved", C.c_int32), ("device_bytes", C.c_int64)]
+                ("leaves_per_step", C.c_int32), ("device_bytes", C.c_int64)]
 
 
 class AzStats(C.Structure):
@@ -41,7 +41,8 @@ EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check"
            "az_set_position", "az_begin_search", "az_select_gather", "az_expand_backup", "az_expand_select", "az_root_policy",
            "az_root_nn_state", "az_play_moves", "az_game_info", "az_emit_samples", "az_read_stats",
            "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_heads_forward", "az_heads_feat_stride", "az_augment_samples", "az_leaf_buffers", "az_compact_leaves", "az_copy_to_host",
-           "az_tower_heads_forward_static", "az_static_max_boards", "az_tower_forward_f32", "az_heads_forward_f32"]
+           "az_tower_heads_forward_static", "az_static_max_boards", "az_tower_forward_f32", "az_heads_forward_f32",
+           "az_select_wave", "az_expand_wave", "az_search_remaining", "az_set_virtual_loss"]
 
 _lib = None
 
@@ -91,6 +92,10 @@ def load_library() -> C.CDLL:
     lib.az_tower_heads_forward_static.argtypes = [C.c_int32] * 4 + [vp] * 14 + [C.c_float, vp, vp, vp]
     lib.az_tower_forward_f32.argtypes = [C.c_int32] * 4 + [vp] * 10 + [C.c_int32, vp]
     lib.az_heads_forward_f32.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
+    lib.az_select_wave.argtypes = [vp, vp, C.c_int32, vp]
+    lib.az_expand_wave.argtypes = [vp, vp, vp, vp, vp]
+    lib.az_search_remaining.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp]
+    lib.az_set_virtual_loss.argtypes = [vp, C.c_double]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
     for name in EXPORTS:
@@ -154,7 +159,10 @@ class Engine:
     """Many concurrent games, one search tree each, resident on one GPU."""
 
     def __init__(self, game: int, n_slots: int, max_sims: int, board_size: int = 15, c_puct: float = 1.0,
-                 epsilon: float = 0.25, nn_dtype: torch.dtype = torch.float32, device=None, edge_cap: int = 0):
+                 epsilon: float = 0.25, nn_dtype: torch.dtype = torch.float32, device=None, edge_cap: int = 0,
+                 leaves_per_step: int = 1, virtual_loss: float = 0.3):
+        """leaves_per_step K > 1: virtual loss / in-tree leaf batching (select_wave / expand_wave); the per-simulation
+        batch then has n_slots * K rows (``rows``)."""
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: the engine has no CPU path")
@@ -165,7 +173,7 @@ class Engine:
         self.device = torch.device("cuda", dev_index)
         self.nn_dtype = nn_dtype
         cfg = AzConfig(game, board_size, n_slots, max_sims, c_puct, epsilon, _NN_DTYPES[nn_dtype], dev_index,
-                       edge_cap, 0)
+                       edge_cap, leaves_per_step)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             rc = self.lib.az_create(C.byref(cfg), C.byref(h))
@@ -179,6 +187,10 @@ class Engine:
         self.game = game
         self.n_slots = n_slots
         self.max_sims = max_sims
+        self.leaves_per_step = max(int(d.leaves_per_step), 1)
+        self.rows = n_slots * self.leaves_per_step  # rows of the NN batch / logits / values / packed leaf batch
+        if self.leaves_per_step > 1:
+            self._ck(self.lib.az_set_virtual_loss(self._h, C.c_double(virtual_loss)))
 
     # ------------------------------------------------------------------ plumbing
     def _ck(self, rc):
@@ -211,9 +223,30 @@ class Engine:
 
     def new_nn_input(self):
         d = self.dims
-        return torch.zeros(self.n_slots, d.nn_channels, d.height, d.width, dtype=self.nn_dtype, device=self.device)
+        return torch.zeros(self.rows, d.nn_channels, d.height, d.width, dtype=self.nn_dtype, device=self.device)
 
     # ------------------------------------------------------------------ entry points
+    def select_wave(self, sims_target: int, nn_input=None):
+        """up to K descents per tree with virtual loss (az_select_wave); leaf j of slot g is row g*K + j"""
+        d = self.dims
+        self._expect(nn_input, (self.rows, d.nn_channels, d.height, d.width), self.nn_dtype, "nn_input")
+        self._ck(self.lib.az_select_wave(self._h, _ptr(nn_input), int(sims_target), self._stream()))
+
+    def expand_wave(self, logits, values, noise=None):
+        A = self.dims.n_action
+        self._expect(logits, (self.rows, A), torch.float32, "logits")
+        if values.dim() == 2:
+            values = values.view(-1)
+        self._expect(values, (self.rows,), torch.float32, "values")
+        self._expect(noise, (self.n_slots, A), torch.float32, "noise")
+        self._ck(self.lib.az_expand_wave(self._h, _ptr(logits), _ptr(values), _ptr(noise), self._stream()))
+
+    def search_remaining(self, sims_target: int):
+        """-> (simulations left over all active trees, the most any one tree has left); synchronises"""
+        tot, mx = C.c_int64(0), C.c_int32(0)
+        self._ck(self.lib.az_search_remaining(self._h, int(sims_target), C.byref(tot), C.byref(mx), self._stream()))
+        return int(tot.value), int(mx.value)
+
     def check(self):
         self._ck(self.lib.az_check(self._h, self._stream()))
 
@@ -244,7 +277,7 @@ class Engine:
     def select_gather(self, nn_input=None):
         """nn_input None: only the packed leaf batch is produced (what the fused tower reads)"""
         d = self.dims
-        self._expect(nn_input, (self.n_slots, d.nn_channels, d.height, d.width), self.nn_dtype, "nn_input")
+        self._expect(nn_input, (self.rows, d.nn_channels, d.height, d.width), self.nn_dtype, "nn_input")
         self._ck(self.lib.az_select_gather(self._h, _ptr(nn_input), self._stream()))
 
     def expand_backup(self, logits, values, noise=None):

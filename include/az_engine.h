@@ -51,7 +51,9 @@ typedef struct az_config {
   int32_t nn_dtype;    /* AZ_NN_*: element type of the NN-input batch the engine writes */
   int32_t device;      /* HIP device ordinal */
   int32_t edge_cap;    /* child records per tree; 0 = worst case max_sims * A */
-  int32_t reserved;
+  int32_t leaves_per_step; /* 0 or 1: the reference's sequential search (one leaf per tree per step); 2 .. 16: virtual loss /
+                              in-tree leaf batching (INFER_BATCH_SIZE, config/basic.py:28) through az_select_wave /
+                              az_expand_wave -- the per-simulation batch then has n_slots * leaves_per_step rows */
 } az_config;
 
 typedef struct az_dims {
@@ -63,7 +65,7 @@ typedef struct az_dims {
   int32_t state_words;    /* u32 words of one bitboard state */
   int32_t edge_cap, node_cap, depth_cap;
   int32_t n_slots;
-  int32_t reserved;
+  int32_t leaves_per_step; /* K >= 1: rows per slot in the NN batch, logits, values and the packed leaf batch */
   int64_t device_bytes;   /* HBM held by the engine */
 } az_dims;
 
@@ -135,6 +137,27 @@ int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_
  * last backup of a move can go out this way (half the tree launches).  Same arguments and results as the two calls. */
 int az_expand_select(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev,
                      void *nn_input_dev, void *stream);
+
+/* Virtual loss / in-tree leaf batching, for engines created with leaves_per_step K > 1.  The reference carries the
+ * hooks -- MCTSNode.pending / .virtual_loss (core/MCTS_alphazero.py:32-33), `q - child.virtual_loss / (child.visits + 1)`
+ * in select (:70), USE_VIRTUAL_LOSS / VIRTUAL_LOSS = 0.3 / INFER_BATCH_SIZE (config/basic.py:19-30) -- but no code that
+ * sets them, so the rule is defined here (and restated in oracle/az_oracle.c: az_oracle_search_wave):
+ *   az_select_wave: every active tree makes up to min(K, sims_target - simulations done) descents, one after the other;
+ *   a child's virtual loss is VIRTUAL_LOSS x (descents already queued in this call that pass through it); tree
+ *   statistics do not change inside the call; a descent that ends on a leaf already queued closes the tree's wave and is
+ *   dropped.  Leaf j of slot g is row g*K + j of nn_input_dev ((n_slots*K, nn_channels, height, width), may be NULL) and
+ *   of the packed leaf batch / flags (az_leaf_buffers; rows of unused j have flag 0).
+ *   az_expand_wave: logits_dev (n_slots*K, A), values_dev (n_slots*K): every tree's queued leaves are expanded (or, if
+ *   terminal, valued by rule) and backed up in queue order; noise_dev (n_slots, A) or NULL as for az_expand_backup.
+ *   az_search_remaining: synchronises; *sum_out = simulations still to run over all active trees for a search of
+ *   sims_target simulations, *max_out = the most any one tree has left (either may be NULL).  Loop select_wave ->
+ *   network -> expand_wave until it reports 0.
+ * With K == 1 the pair is az_select_gather / az_expand_backup bit for bit.  The sequential entry points are refused on a
+ * K > 1 engine. */
+int az_select_wave(az_engine *e, void *nn_input_dev, int32_t sims_target, void *stream);
+int az_expand_wave(az_engine *e, const float *logits_dev, const float *values_dev, const float *noise_dev, void *stream);
+int az_search_remaining(az_engine *e, int32_t sims_target, int64_t *sum_out, int32_t *max_out, void *stream);
+int az_set_virtual_loss(az_engine *e, double virtual_loss); /* > 0 (config/basic.py:46-47); default 0.3 */
 
 /* core/MCTS_alphazero.py:174-178: pi = visits / visits.sum() as (n_slots, A) f32.  Optional extras
  * (NULL to skip): root child visits i32 (n_slots, A), child values f64 (n_slots, A) from the child's

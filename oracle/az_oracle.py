@@ -125,6 +125,27 @@ def search(game, board_size, root_state, root_player, history, num_sim, eval_fn,
                 leaf_prior=leaf_prior, stats=stats)
 
 
+def search_wave(game, board_size, root_state, root_player, history, num_sim, leaves_per_wave, eval_fn, ctx=None,
+                virtual_loss=0.3, c_puct=1.0, epsilon=0.25, noise=None):
+    """the search with virtual loss / in-tree leaf batching (az_oracle_search_wave); leaves_per_wave == 1 is search()"""
+    d = dims(game, board_size)
+    A = d["A"]
+    root_state = np.ascontiguousarray(root_state, np.float32).reshape(-1)
+    history = np.ascontiguousarray(history, np.float32).reshape(-1)
+    noise = None if noise is None else np.ascontiguousarray(noise, np.float32).reshape(-1)
+    pi, visits = np.zeros(A, np.float32), np.zeros(A, np.int32)
+    child_q, root_prior, stats = np.zeros(A, np.float64), np.zeros(A, np.float32), np.zeros(5, np.float64)
+    fn = lib().az_oracle_search_wave
+    fn.restype = C.c_int
+    rc = fn(C.c_int(game), C.c_int(board_size), _p(root_state, _f32p), C.c_int(root_player), _p(history, _f32p),
+            C.c_int(num_sim), C.c_int(leaves_per_wave), C.c_double(virtual_loss), C.c_float(c_puct), C.c_float(epsilon),
+            _p(noise, _f32p), eval_fn, ctx, _p(pi, _f32p), _p(visits, _i32p), _p(child_q, _f64p), _p(root_prior, _f32p),
+            _p(stats, _f64p))
+    if rc != 0:
+        raise RuntimeError(f"az_oracle_search_wave failed: {rc}")
+    return dict(pi=pi, visits=visits, child_q=child_q, root_prior=root_prior, stats=stats)
+
+
 def self_play(game, board_size, num_sim, tao, expo, eval_fn, ctx=None, noise=None, c_puct=1.0,
               epsilon=0.25, max_plies=None, want_states=True):
     d = dims(game, board_size)
