@@ -151,8 +151,19 @@ class SelfPlayRunner:
         torch.cuda.current_stream(self.e.device).wait_stream(s)
         torch.cuda.synchronize(self.e.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.eval_step(noise)
+        # No garbage collection inside the capture: a stale Engine (or any tensor) finalised there frees device memory,
+        # which a stream capture in progress does not survive ("operation failed due to a previous error during capture").
+        import gc
+
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g):
+                self.eval_step(noise)
+        finally:
+            if was_enabled:
+                gc.enable()
         self._graph, self._graph_noise = g, noise is not None
 
     def search(self) -> None:
