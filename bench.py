@@ -147,7 +147,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     torch.manual_seed(1234 + rank)  # same weights on every rank (make_model seeds 0), different games: per-rank RNG streams
     torch.cuda.manual_seed(1234 + rank)
 
-    eng = Engine(game, slots, sims, board_size=n, nn_dtype=tdtype, device=dev)
+    eng = Engine(game, slots, sims, board_size=n, nn_dtype=tdtype, device=dev, leaves_per_step=max(args.leaves, 1))
     d = eng.dims
     evaluator = args.evaluator
     if evaluator == "auto":
@@ -158,6 +158,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))
     if evaluator == "hash":  # tree kernels alone (no network)
         run.evaluate = lambda: eng.eval_hash(run.nn_input, run.logits, run.values, 6.0)
+    wave = eng.leaves_per_step > 1  # virtual loss / in-tree leaf batching: several leaves per tree per network batch
     ring = HostSampleRing(max(4 * slots, 65536), (d.nn_channels, d.height, d.width), d.n_action)
     esize = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}[tdtype]
 
@@ -257,7 +258,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     def step(timed: bool):
         if publisher.publish(force=args.force_dist) and run.fused is not None:  # learner -> self-play weight push (RCCL broadcast; no-op at N = 1)
             run.fused.refresh()  # re-fold BatchNorm / re-pack the published weights for the fused tower
-        done = timed_round() if (timed and not args.graph) else run.move_round(inv_tao)[1]
+        done = timed_round() if (timed and not args.graph and not wave) else run.move_round(inv_tao)[1]
         finalize_pending()  # the previous move's samples -> the host ring, under the search just queued
         collect(done)
 
@@ -282,7 +283,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     elapsed = time.perf_counter() - t0
     eng.check()
     st = eng.read_stats()
-    if args.graph:  # kernel times: one eager, event-bracketed probe step outside the timed region
+    if args.graph and not wave:  # kernel times: one eager, event-bracketed probe step outside the timed region
         eng.reset_stats()
         keep = (finished_games, finished_plies)
         collect(timed_round())
@@ -311,6 +312,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     nn_ms_raw = sum(a.elapsed_time(b) for a, b in ev_nn) / max(len(ev_nn), 1)
     tower_ms_raw = sum(a.elapsed_time(b) for a, b in ev_tower) / max(len(ev_tower), 1) if ev_tower else None
     has_fused = run.fused is not None
+    eng_k = eng.leaves_per_step
     del run, ring, pending
     eng.close()
     del eng
@@ -321,7 +323,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     # with the full search: measured here on a small population, outside the timed region.
     game_len = None
     if rank == 0 and with_probe and args.game_probe > 0 and evaluator != "hash":
-        pe = Engine(game, args.game_probe, sims, board_size=n, nn_dtype=tdtype, device=dev)
+        pe = Engine(game, args.game_probe, sims, board_size=n, nn_dtype=tdtype, device=dev, leaves_per_step=max(args.leaves, 1))
         pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))
         pit = torch.full((args.game_probe,), 1.0 / reference_tao(0), device=dev)
         lengths, moves, tp0 = [], 0, time.perf_counter()
@@ -344,6 +346,21 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
 
     def corr(ms):
         return max(ms - ev_overhead, 1e-6)
+
+    if wave:  # no per-kernel brackets in wave mode (the step count of a move is data dependent): throughput only
+        return {
+            "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {sims} sims/move, {slots} concurrent games per GPU, evaluator={evaluator} "
+                                   f"({dtype_name} network arithmetic), virtual loss with {eng_k} leaves per tree per network batch "
+                                   "(az_select_wave / az_expand_wave; NOT the reference's sequential search)",
+                       "slots_per_gpu": slots, "sims_per_move": sims, "leaves_per_step": eng_k,
+                       "parallelism": f"games sharded x{world}, no data-path collective"},
+            "plies_per_sec": slots * world * steps / elapsed,
+            "games_per_sec": (slots * world * steps / elapsed / game_len["mean_plies"]) if game_len else None,
+            "game_length": game_len, "roofline": None,
+            "evals_per_sim": st["evals"] / max(st["sims"], 1), "mean_depth": st["sum_depth"] / max(st["sims"], 1)}
 
     peak = PEAK_TFLOPS[dtype_name]
     nin = d.nn_channels * d.height * d.width
@@ -527,6 +544,8 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: the timed steps replay the simulation step as a captured HIP graph "
                     "(what the small, launch-bound games want); the per-kernel HIP-event times then come from one eager probe "
                     "step run after the timed region.  0 (default): eager launches, events inside the timed region")
+    ap.add_argument("--leaves", type=int, default=1, help="leaves per tree per network batch: > 1 = virtual loss / in-tree leaf "
+                    "batching (az_select_wave / az_expand_wave), which is not the reference's sequential search; reported without roofline")
     ap.add_argument("--preroll", type=int, default=96, help="cheap 2-sim move rounds that stagger game ages")
     ap.add_argument("--game-probe", type=int, default=1024, help="games played start to finish (full search, outside the timed "
                     "region, rank 0) to measure the mean game length that converts plies/s into games/s; 0 = skip")
@@ -566,7 +585,7 @@ def main():
     out = measure(args, primary, args.steps, args.warmup, dev, rank, world, use_dist)
     sec_steps = args.secondary_steps if args.secondary_steps >= 0 else (min(args.steps, 4) if world == 1 else 0)
     second = None
-    if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused"):
+    if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1:
         second = measure(args, "bf16", sec_steps, 1, dev, rank, world, use_dist)
     if rank == 0:
         out["cpu_baseline"] = cpu

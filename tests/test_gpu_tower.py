@@ -184,3 +184,47 @@ def test_packed_leaf_batch_equals_dense_planes(board, ch):
     touched4 = ev._buf[G][0][:, 0] >= 0
     assert torch.equal(touched4, touched)
     assert torch.equal(p4[touched], p1[touched]) and torch.equal(v4[touched], v1[touched])
+
+
+@pytest.mark.parametrize("precision,board,G", [("bf16", 15, 1400), ("bf16", 9, 3400), ("f32", 15, 1400), ("f32", 9, 3400)])
+def test_zero_block_tower_packed_flags_many_tickets(precision, board, G):
+    """blocks = 0 (stem + heads only: no conv layer, hence no stage barrier, between the fetch of the next group's
+    ticket / slots / input and their use) in packed + flags mode with more groups than workgroups, so every workgroup
+    draws several tickets: == the dense-plane route row by row."""
+    from alphazero_amd import Engine
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(1)
+    dt = torch.bfloat16 if precision == "bf16" else torch.float32
+    ev = FusedTowerEvaluator(_randomised(GomokuNet(board, 64, 0)).eval().cuda(), precision)
+    sims = 6
+    eng = Engine(2, G, sims, board_size=board, nn_dtype=dt, device="cuda:0")
+    nn = eng.new_nn_input()
+    A = board * board
+    logits, values = eng.new(G, A), eng.new(G)
+    it = torch.ones(G, device="cuda")
+    for _ in range(3):
+        eng.begin_search()
+        for _ in range(sims):
+            eng.select_gather(nn)
+            eng.eval_hash(nn, logits, values, 6.0)
+            eng.expand_backup(logits, values, None)
+        eng.play_moves(it, torch.empty(G, A, device="cuda").exponential_(1))
+    eng.begin_search()
+    for _ in range(4):
+        eng.select_gather(nn)
+        eng.eval_hash(nn, logits, values, 6.0)
+        eng.expand_backup(logits, values, None)
+    eng.select_gather(nn)
+    p1, v1 = ev(nn)
+    p1, v1 = p1.clone(), v1.clone()
+    ring, leaf, _, _, flg = eng.leaf_buffers()
+    for _ in range(3):  # several launches: a stale ticket or slot would show up as a wrong or missing row
+        for t in ev._buf[G]:
+            t.fill_(-1.0)
+        p2, v2 = ev(None, packed=(ring, leaf, None, None, flg), n_boards=G)
+        touched = ev._buf[G][0][:, 0] >= 0
+        assert int(touched.sum()) == G  # no terminal leaves this early: every slot is flagged
+        assert torch.equal(p2, p1) and torch.equal(v2, v1)
+    eng.check()
