@@ -23,6 +23,7 @@
 // (8 bitboards + player) or dense f32 planes.  C ABI at the bottom; declared in include/az_engine.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <string>
@@ -359,6 +360,332 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 15x15 boards: the same tower on v_mfma_f32_16x16x4_f32 with 16-cell tiles.  225 cells = 14 tiles of 16 + ONE cell, where
+// eight 32-cell tiles spend 12 % of the MFMA time on 31 padding cells.  Wave w owns cell tiles 7 (w & 1) .. + 6 and the 32
+// output channels 32 (w >> 1) .. + 31: 7 x 2 accumulator tiles of 16 x 16 (56 registers), 14 per wave, all waves equal.
+// Cell 224 (the corner, four taps on the board) is computed on the VALU from the weight stages that stream through LDS
+// anyway: wave w takes its output channels 16 w .. + 15 in the MFMA's own lane layout (lane = channel x k quarter), two
+// more ds_read_b128 and four fmaf per k-step, in the shadow of the MFMAs.
+// The instruction takes A[co][k = lane >> 4] / B[k = lane >> 4][cell = lane & 15]; a lane of k-quarter kq reads the 16
+// bytes of channels 16 m + 4 kq .. + 3 once and feeds four MFMAs (MFMA t: the k set {16 m + 4 kq' + t}).  Same packed
+// weights as k_tower_f32 ([tap][16-byte chunk of ci][co][4]); a stage is 2 k-steps of 16 channels (8 KiB).
+typedef __attribute__((ext_vector_type(4))) float f32x4a;
+
+template <int KS16, int KPSL, int NEXT_BYTES, bool LEFT>
+__device__ __forceinline__ void conv_layer16(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext, int wave, int lane,
+                                             const int pp0, const unsigned long long vm, f32x4 (&acc)[7][2], float &lc) {
+  constexpr int N = 15, ZERO_OFF = 225 * ROW, LCELL = 224;
+  constexpr int KSB16 = 4 * C * 16;  // bytes of one k-step of 16 channels: [kq 4][co 64][4] f32 = 4 KiB
+  static_assert(KS16 % KPSL == 0, "a stage never straddles two taps");
+  constexpr int SPT = KS16 / KPSL, NSTAGE = 9 * SPT, SB = KPSL * KSB16;
+  const int kq = lane >> 4, r = lane & 15, ch = wave >> 1;
+  const uint32_t act32 = (uint32_t)(uintptr_t)act;
+#pragma unroll 1
+  for (int sg = 0; sg < NSTAGE; ++sg) {
+    const int tap = sg / SPT, ks0 = (sg % SPT) * KPSL;
+    const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
+    uint32_t bb[7];
+#pragma unroll
+    for (int pt = 0; pt < 7; ++pt) {  // (the lane's cells are pp0 + 16 pt; bit 9 pt + tap of vm: that tap is on the board)
+      const uint32_t q = (uint32_t)(pp0 + 16 * pt + d);
+      const uint32_t in = (q << 8) | (((q & 15u) ^ (uint32_t)kq) << 4);
+      bb[pt] = ((vm >> (9 * pt + tap)) & 1ull) ? in : (uint32_t)(ZERO_OFF | (kq << 4));
+    }
+    const char *wst = wbuf + ((buf + sg) & 1) * STAGE_BYTES;
+    const uint32_t wa32 = (uint32_t)(uintptr_t)(wst + kq * (C * 16) + (ch * 32 + r) * 16);
+    // One register set: the exposed LDS round trip of a k-step (a few hundred cycles against 56 MFMAs = 1,792) is covered by
+    // the partner wave of the SIMD -- the MFMA pipe is the bound, and each of the two waves only has to feed it half the time.
+    // Fragment reads run half a k-step ahead of the MFMAs that use them, through two register groups that are re-used
+    // as soon as their MFMAs have been issued: group A = weights of both channel tiles + cell tiles 0..3 (+ the two
+    // operands of cell 224), group B = cell tiles 4..6.  While the 32 MFMAs of group A run, group B's reads (and then the
+    // next k-step's group A) are on their way, and vice versa: only a stage's first reads are exposed.
+    // (Two waves share a SIMD's MFMA pipe; they tend to run in lockstep -- equal work, alternating issue -- so an exposed
+    // round trip is NOT reliably covered by the partner: with every k-step's reads exposed the pipe idled 20 % of the time.)
+    f32x4 fa[2][2], fbA[4], fbB[3], lw, lx;
+    // cell 224 on the VALU: wave w computes its output channels 16 w .. 16 w + 15, lane (r, kq) the products of channel
+    // 16 w + r with the input channels 16 m + 4 kq .. + 3 (the MFMA's own lane layout; the four k quarters are summed by
+    // a lane butterfly after the layer).  Taps with dr <= 0 and dc <= 0 are on the board for that corner cell; the others
+    // read the zero row.
+    const bool ltap = LEFT && tap / 3 <= 1 && tap % 3 <= 1;
+    const uint32_t lw32 = (uint32_t)(uintptr_t)(wst + kq * (C * 16) + (wave * 16 + r) * 16);
+    const uint32_t lq = (uint32_t)(LCELL + d);
+    const uint32_t lx32 = act32 + (ltap ? ((lq << 8) | (((lq & 15u) ^ (uint32_t)kq) << 4)) : (uint32_t)(ZERO_OFF | (kq << 4)));
+    auto loadA = [&](int i) {  // 8 reads
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i & 1][0]) : "v"(wa32), "i"(i * KSB16));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i & 1][1]) : "v"(wa32), "i"(i * KSB16 + 256));
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fbA[pt]) : "v"(act32 + (bb[pt] ^ (uint32_t)((ks0 + i) << 6))));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lw) : "v"(lw32), "i"(i * KSB16));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(lx) : "v"(lx32 ^ (uint32_t)((ks0 + i) << 6)));
+    };
+    auto loadB = [&](int i) {  // 3 reads
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fbB[pt]) : "v"(act32 + (bb[4 + pt] ^ (uint32_t)((ks0 + i) << 6))));
+    };
+    loadA(0);
+#pragma unroll
+    for (int i = 0; i < KPSL; ++i) {
+      loadB(i);
+      asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");  // group A of k-step i has returned
+      __builtin_amdgcn_sched_barrier(0);
+      if (LEFT) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lc = fmaf(lw[t], lx[t], lc);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+          acc[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i & 1][0][t], fbA[pt][t], acc[pt][0], 0, 0, 0);
+          acc[pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i & 1][1][t], fbA[pt][t], acc[pt][1], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 0) {  // the DMA of the next stage's weights: on its way under this stage's MFMAs
+        char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
+        if (sg < NSTAGE - 1) stage_w<SB>(wg + (size_t)(sg + 1) * SB, wn, wave, lane);
+        else if (wnext != nullptr) stage_w<NEXT_BYTES>(wnext, wn, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i + 1 < KPSL) {
+        loadA(i + 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // group B of k-step i has returned
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) {
+          acc[4 + pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i & 1][0][t], fbB[pt][t], acc[4 + pt][0], 0, 0, 0);
+          acc[4 + pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i & 1][1][t], fbB[pt][t], acc[4 + pt][1], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next stage has landed
+    __syncthreads();
+  }
+  buf = (buf + NSTAGE) & 1;
+}
+
+__global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restrict__ x, const uint32_t *__restrict__ ring,
+                                                          const int4 *__restrict__ leafrec, const uint8_t *__restrict__ flags, int G,
+                                                          const char *__restrict__ w0, const char *__restrict__ wl,
+                                                          const float *__restrict__ bias, int L, const float *__restrict__ headw,
+                                                          const float *__restrict__ headb, float *__restrict__ feat, int FS,
+                                                          unsigned int *tickets) {
+  constexpr int N = 15, NV = 225, WC = 8, SWB = 16, RGW = 8 * SWB, LCELL = 224, KP = 240;
+  constexpr int ACT_BYTES = NV * ROW + ROW, HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16, RG_BYTES = ((RGW + 3) * 4 + 15) / 16 * 16;
+  constexpr int KSB16 = 4 * C * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *act = smem;
+  char *wbuf = smem + ACT_BYTES;
+  float *hw = (float *)(wbuf + 2 * STAGE_BYTES);
+  uint32_t *rg = (uint32_t *)((char *)hw + HW_BYTES);  // RGW ring words, player, slot, ticket
+  int *slots = (int *)rg + RGW + 1;
+  float *hp = (float *)((char *)rg + RG_BYTES);         // [2 cell halves][7 tiles][16 cells][3]: head sums of the upper-channel waves
+  float *lh = hp + 2 * 7 * 16 * 3;                      // [4 waves][3]: head sums of cell 224
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, ch = wave >> 1, chalf = wave & 1;
+
+  for (int i = tid; i < ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero row
+  for (int i = tid; i < 3 * C + 3; i += 256) hw[i] = i < 3 * C ? headw[i] : headb[i - 3 * C];
+
+  const int pp0 = 7 * chalf * 16 + (lane & 15);  // this lane's cells: pp0 + 16 pt
+  unsigned long long vm = 0;                      // bit 9 pt + tap: tap of that cell is on the board
+#pragma unroll
+  for (int pt = 0; pt < 7; ++pt) {
+    const int cell = pp0 + 16 * pt, row = cell / N, col = cell % N;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int rr = row + t / 3 - 1, cc = col + t % 3 - 1;
+      if (rr >= 0 && rr < N && cc >= 0 && cc < N) vm |= 1ull << (9 * pt + t);
+    }
+  }
+  int buf = 0;
+  stage_w<KSB16>(w0, wbuf, wave, lane);  // the stem's first stage (one tap: 16 padded channels = one k-step)
+  int ticket = (int)blockIdx.x;
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) {
+      for (;;) {
+        const bool on = ticket < G && (flags == nullptr || flags[ticket] != 0);
+        if (on || ticket >= G) break;
+        ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));  // a terminal leaf: one more draw
+      }
+      slots[0] = ticket < G ? ticket : -1;
+      slots[1] = ticket;
+    }
+    __syncthreads();
+    if (slots[1] >= G) break;
+    const int g = slots[0];
+    if (tid == 0) ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));
+    if (x == nullptr) {
+      for (int i = tid; i < RGW + 1; i += 256) rg[i] = i < RGW ? ring[(size_t)g * RGW + i] : (uint32_t)leafrec[g].w;
+      __syncthreads();
+    }
+    if (tid < NV) {
+      const int cell = tid;
+      float c[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) c[k] = 0.0f;
+      if (x != nullptr) {
+        const float *xr = x + (size_t)g * 9 * NV + cell;
+#pragma unroll
+        for (int cc = 0; cc < 9; ++cc) c[cc] = xr[cc * NV];
+      } else {
+        const int wi = cell >> 5, sh = cell & 31;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          c[k] = (float)(int)((rg[k * SWB + wi] >> sh) & 1u) - (float)(int)((rg[k * SWB + WC + wi] >> sh) & 1u);
+        c[8] = (int)rg[RGW] > 0 ? 1.0f : -1.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *(f32x4 *)(act + act_addr(cell, k)) = (f32x4){c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x4 acc[7][2], res[7][2];
+    float lc = 0.0f, lres = 0.0f;  // cell 224: output channel lco of this wave's 16, partial over this lane's k quarter
+    const int lco = wave * 16 + (lane & 15);
+    float *const lptr = (float *)(act + act_addr(LCELL, lco >> 2) + (lco & 3) * 4);
+    auto init = [&](const float *b, bool with_res) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 bv = *(const f32x4 *)(b + ch * 32 + ct * 16 + kq * 4);
+#pragma unroll
+        for (int pt = 0; pt < 7; ++pt) acc[pt][ct] = with_res ? bv + res[pt][ct] : bv;
+      }
+      lc = 0.0f;
+    };
+    auto lfinal = [&](const float *b, bool with_res) {  // the four k quarters of cell 224, then bias (+ residual)
+      lc = lc + __shfl_xor(lc, 16, 64);
+      lc = lc + __shfl_xor(lc, 32, 64);
+      lc = (with_res ? b[lco] + lres : b[lco]) + lc;
+    };
+    auto epilogue = [&]() {
+#pragma unroll
+      for (int pt = 0; pt < 7; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[pt][ct][j], 0.0f);
+          *(f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + ct) * 4 + kq)) = v;
+        }
+      if (kq == 0) *lptr = fmaxf(lc, 0.0f);
+    };
+    // ---- stem
+    init(bias, false);
+    if (L > 0) conv_layer16<1, 1, 2 * KSB16, true>(act, wbuf, buf, w0, wl, wave, lane, pp0, vm, acc, lc);
+    else conv_layer16<1, 1, KSB16, true>(act, wbuf, buf, w0, w0, wave, lane, pp0, vm, acc, lc);
+    lfinal(bias, false);
+    if (L > 0) {
+      epilogue();
+      __syncthreads();
+    }
+    // ---- residual blocks
+    for (int l = 0; l < L; l += 2) {
+#pragma unroll
+      for (int pt = 0; pt < 7; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) res[pt][ct] = *(const f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + ct) * 4 + kq));
+      lres = *lptr;
+      init(bias + (1 + l) * C, false);
+      conv_layer16<4, 2, 2 * KSB16, true>(act, wbuf, buf, wl + (size_t)l * 9 * 4 * KSB16, wl + (size_t)(l + 1) * 9 * 4 * KSB16, wave, lane, pp0, vm,
+                                            acc, lc);
+      lfinal(bias + (1 + l) * C, false);
+      epilogue();
+      __syncthreads();
+      init(bias + (2 + l) * C, true);
+      if (l + 2 < L) {
+        conv_layer16<4, 2, 2 * KSB16, true>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * 4 * KSB16, wl + (size_t)(l + 2) * 9 * 4 * KSB16, wave, lane,
+                                              pp0, vm, acc, lc);
+        lfinal(bias + (2 + l) * C, true);
+        epilogue();
+        __syncthreads();
+      } else {
+        conv_layer16<4, 2, KSB16, true>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * 4 * KSB16, w0, wave, lane, pp0, vm, acc, lc);
+        lfinal(bias + (2 + l) * C, true);
+      }
+    }
+    // ---- heads: 1x1 convs + ReLU from the accumulators.  A lane holds 8 of its cell's channels (2 channel tiles x 4), the
+    // four k-quarter groups of a wave hold the 32 channels of its half, the other half sits in wave ^ 2.
+    {
+      float hs[7][3];
+#pragma unroll
+      for (int pt = 0; pt < 7; ++pt) hs[pt][0] = hs[pt][1] = hs[pt][2] = 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x4 wv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wv[k] = *(const f32x4 *)(hw + k * C + ch * 32 + ct * 16 + kq * 4);
+#pragma unroll
+        for (int pt = 0; pt < 7; ++pt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = fmaxf(acc[pt][ct][j], 0.0f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) hs[pt][k] = fmaf(a, wv[k][j], hs[pt][k]);
+          }
+      }
+#pragma unroll
+      for (int pt = 0; pt < 7; ++pt)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // sum over the four k-quarter groups (same order on every lane of a cell)
+          float t = hs[pt][k];
+          t = t + __shfl_xor(t, 16, 64);
+          t = t + __shfl_xor(t, 32, 64);
+          hs[pt][k] = t;
+        }
+      {  // cell 224: this wave's 16 channels (lanes of k quarter 0), butterfly over those lanes, partial per wave to LDS
+        const float a = kq == 0 ? fmaxf(lc, 0.0f) : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float t = a * hw[k * C + lco];
+#pragma unroll
+          for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+          if (lane == 0) lh[wave * 3 + k] = t;
+        }
+      }
+      if (ch == 1 && kq == 0) {
+#pragma unroll
+        for (int pt = 0; pt < 7; ++pt)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) hp[((chalf * 7 + pt) * 16 + (lane & 15)) * 3 + k] = hs[pt][k];
+      }
+      __syncthreads();
+      float *fr = feat + (size_t)g * FS;
+      if (ch == 0) {
+#pragma unroll
+        for (int pt = 0; pt < 7; ++pt) {
+          if ((pt & 3) != kq) continue;  // the four k-quarter groups share the stores
+          const int cell = (pp0 + 16 * pt);
+          const float *o = hp + ((chalf * 7 + pt) * 16 + (lane & 15)) * 3;
+          fr[cell] = fmaxf(hs[pt][0] + o[0] + hw[3 * C + 0], 0.0f);
+          fr[KP + cell] = fmaxf(hs[pt][1] + o[1] + hw[3 * C + 1], 0.0f);
+          fr[KP + NV + cell] = fmaxf(hs[pt][2] + o[2] + hw[3 * C + 2], 0.0f);
+        }
+      }
+      if (wave == 3 && lane < 3) {
+        const int k = lane;
+        const float t = ((lh[k] + lh[3 + k]) + lh[6 + k]) + lh[9 + k];
+        fr[(k == 0 ? 0 : KP + (k - 1) * NV) + LCELL] = fmaxf(t + hw[3 * C + k], 0.0f);
+      }
+    }
+  }
+  if (tid == 0 && atomicAdd(&tickets[1], 1u) == gridDim.x - 1) {
+    tickets[0] = 0u;
+    tickets[1] = 0u;
+    __threadfence();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The heads' Linear layers in f32 (examples/gomoku/model.py:69-90): logits = feat[:, :NV] @ Wp^T + bp;
 // value = tanh(relu(feat[:, KP:KP+2NV] @ W1^T + b1) @ w2 + b2), as f32 MFMA GEMMs read straight from L2.  One workgroup = 32
 // boards x one job (blockIdx.y: four policy output tiles, one per wave | the value head).  A = features (lane: board
@@ -505,7 +832,10 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
     return AZ_OK;
   };
   int rc;
-  if (board_size == 15) rc = launch(k_tower_f32<15, 1>, GeoF<15, 1>::lds_bytes(), 1, 0);
+  constexpr size_t LDS_T16 = (size_t)(225 * ROW + ROW) + 2 * STAGE_BYTES + ((3 * C + 3) * 4 + 15) / 16 * 16 + ((128 + 3) * 4 + 15) / 16 * 16 + 2 * 7 * 16 * 3 * 4 + 64;
+  static const bool use32 = getenv("AZ_TOWER_F32_TILE32") != nullptr;  // diagnostic: the 32-cell-tile kernel on 15x15 too
+  if (board_size == 15 && !use32) rc = launch(k_tower_f32_t16, LDS_T16, 1, 2);
+  else if (board_size == 15) rc = launch(k_tower_f32<15, 1>, GeoF<15, 1>::lds_bytes(), 1, 0);
   else rc = launch(k_tower_f32<9, 3>, GeoF<9, 3>::lds_bytes(), 3, 1);
   if (rc != AZ_OK) return rc;
   const hipError_t err = hipGetLastError();
