@@ -368,106 +368,122 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32(const float *__restrict__ 
 // more ds_read_b128 and four fmaf per k-step, in the shadow of the MFMAs.
 // The instruction takes A[co][k = lane >> 4] / B[k = lane >> 4][cell = lane & 15]; a lane of k-quarter kq reads the 16
 // bytes of channels 16 m + 4 kq .. + 3 once and feeds four MFMAs (MFMA t: the k set {16 m + 4 kq' + t}).  Same packed
-// weights as k_tower_f32 ([tap][16-byte chunk of ci][co][4]); a stage is 2 k-steps of 16 channels (8 KiB).
-typedef __attribute__((ext_vector_type(4))) float f32x4a;
+// weights as k_tower_f32 ([tap][16-byte chunk of ci][co][4]).
+// Diagnostic build only (-DAZ_F32_STAMP=1): s_memtime stamps of one steady-state board of workgroup 7, per wave, into a
+// buffer of their own (read back with az_debug_f32_stamps); the product build executes no stamp.
+#ifndef AZ_F32_STAMP
+#define AZ_F32_STAMP 0
+#endif
+#if AZ_F32_STAMP
+static __device__ unsigned long long g_f32_stamps[4 * 32];
+static __device__ unsigned long long g_f32_wg[1024 * 4];  // per workgroup: realtime start, end, boards, HW_ID
+#define FSTAMP(k) do { if (stamp_on && lane == 0) g_f32_stamps[wave * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
+constexpr int T16_MAX_LAYERS = 40;  // bias rows the 16-cell-tile kernel keeps in LDS (deeper towers run on k_tower_f32)
 
-template <int KS16, int KPSL, int NEXT_BYTES, bool LEFT>
-__device__ __forceinline__ void conv_layer16(const char *act, char *wbuf, int &buf, const char *wg, const char *wnext, int wave, int lane,
-                                             const int pp0, const unsigned long long vm, f32x4 (&acc)[7][2], float &lc) {
+// One layer.  The weight fragments are read straight from global memory (L2-resident: 0.6 MB for the whole tower) into
+// registers, one k-step ahead of their MFMAs, not through an LDS stage shared by the workgroup: a staged layer needs a
+// workgroup barrier per stage (18 per layer) and LDS-DMA issues between the MFMAs; this way there is ONE barrier per layer
+// (the in-place epilogue must wait for every wave's reads) and nothing but fragment reads between MFMAs.  (Measured equal
+// within 1 % to the staged version, 8.34 vs 8.39 ms, with 14 KB less LDS.)  The activation fragments run half a k-step
+// ahead through two register groups that are re-used as soon as their MFMAs have been issued: group A = cell tiles 0..3 +
+// the operand of cell 224, group B = cell tiles 4..6; with every k-step's reads exposed the MFMA pipe idled 20 % of the
+// launch (the partner wave of the SIMD does not reliably cover them).
+struct WFrag { f32x4 a0, a1, l; };  // a lane's weights of one k-step: both channel tiles + its row for cell 224
+
+__device__ __forceinline__ void wload(WFrag &w, const char *wlane, const char *llane, int kk) {
+  w.a0 = *(const f32x4 *)(wlane + (size_t)kk * 4096);
+  w.a1 = *(const f32x4 *)(wlane + (size_t)kk * 4096 + 256);
+  w.l = *(const f32x4 *)(llane + (size_t)kk * 4096);
+}
+
+// On entry wf[0] holds (or is about to receive) k-step 0 of this layer; the weights of wnext's k-step 0 are requested
+// during the last k-step, into wf[KSTEPS & 1].  KS16 = k-steps per tap.  No barrier inside: the caller synchronises.
+template <int KSTEPS, int KS16, bool LEFT>
+__device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, const char *wnext, int wave, int lane, const int pp0,
+                                              const unsigned long long vm, f32x4 (&acc)[7][2], float &lc, WFrag (&wf)[2]) {
   constexpr int N = 15, ZERO_OFF = 225 * ROW, LCELL = 224;
-  constexpr int KSB16 = 4 * C * 16;  // bytes of one k-step of 16 channels: [kq 4][co 64][4] f32 = 4 KiB
-  static_assert(KS16 % KPSL == 0, "a stage never straddles two taps");
-  constexpr int SPT = KS16 / KPSL, NSTAGE = 9 * SPT, SB = KPSL * KSB16;
   const int kq = lane >> 4, r = lane & 15, ch = wave >> 1;
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
-#pragma unroll 1
-  for (int sg = 0; sg < NSTAGE; ++sg) {
-    const int tap = sg / SPT, ks0 = (sg % SPT) * KPSL;
+  const int woff = kq * (C * 16) + (ch * 32 + r) * 16, loff = kq * (C * 16) + (wave * 16 + r) * 16;
+  const char *wlane = wg + woff, *llane = wg + loff;
+  uint32_t bb[7], lx32 = 0;
+  auto tap_bb = [&](int tap, int pt) -> uint32_t {  // (the lane's cells are pp0 + 16 pt; bit 9 pt + tap of vm: that tap is on the board)
     const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
-    uint32_t bb[7];
+    const uint32_t q = (uint32_t)(pp0 + 16 * pt + d);
+    const uint32_t in = (q << 8) | (((q & 15u) ^ (uint32_t)kq) << 4);
+    return ((vm >> (9 * pt + tap)) & 1ull) ? in : (uint32_t)(ZERO_OFF | (kq << 4));
+  };
+  auto set_tap_A = [&](int tap) {
 #pragma unroll
-    for (int pt = 0; pt < 7; ++pt) {  // (the lane's cells are pp0 + 16 pt; bit 9 pt + tap of vm: that tap is on the board)
-      const uint32_t q = (uint32_t)(pp0 + 16 * pt + d);
-      const uint32_t in = (q << 8) | (((q & 15u) ^ (uint32_t)kq) << 4);
-      bb[pt] = ((vm >> (9 * pt + tap)) & 1ull) ? in : (uint32_t)(ZERO_OFF | (kq << 4));
-    }
-    const char *wst = wbuf + ((buf + sg) & 1) * STAGE_BYTES;
-    const uint32_t wa32 = (uint32_t)(uintptr_t)(wst + kq * (C * 16) + (ch * 32 + r) * 16);
-    // One register set: the exposed LDS round trip of a k-step (a few hundred cycles against 56 MFMAs = 1,792) is covered by
-    // the partner wave of the SIMD -- the MFMA pipe is the bound, and each of the two waves only has to feed it half the time.
-    // Fragment reads run half a k-step ahead of the MFMAs that use them, through two register groups that are re-used
-    // as soon as their MFMAs have been issued: group A = weights of both channel tiles + cell tiles 0..3 (+ the two
-    // operands of cell 224), group B = cell tiles 4..6.  While the 32 MFMAs of group A run, group B's reads (and then the
-    // next k-step's group A) are on their way, and vice versa: only a stage's first reads are exposed.
-    // (Two waves share a SIMD's MFMA pipe; they tend to run in lockstep -- equal work, alternating issue -- so an exposed
-    // round trip is NOT reliably covered by the partner: with every k-step's reads exposed the pipe idled 20 % of the time.)
-    f32x4 fa[2][2], fbA[4], fbB[3], lw, lx;
-    // cell 224 on the VALU: wave w computes its output channels 16 w .. 16 w + 15, lane (r, kq) the products of channel
-    // 16 w + r with the input channels 16 m + 4 kq .. + 3 (the MFMA's own lane layout; the four k quarters are summed by
-    // a lane butterfly after the layer).  Taps with dr <= 0 and dc <= 0 are on the board for that corner cell; the others
-    // read the zero row.
-    const bool ltap = LEFT && tap / 3 <= 1 && tap % 3 <= 1;
-    const uint32_t lw32 = (uint32_t)(uintptr_t)(wst + kq * (C * 16) + (wave * 16 + r) * 16);
-    const uint32_t lq = (uint32_t)(LCELL + d);
-    const uint32_t lx32 = act32 + (ltap ? ((lq << 8) | (((lq & 15u) ^ (uint32_t)kq) << 4)) : (uint32_t)(ZERO_OFF | (kq << 4)));
-    auto loadA = [&](int i) {  // 8 reads
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i & 1][0]) : "v"(wa32), "i"(i * KSB16));
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i & 1][1]) : "v"(wa32), "i"(i * KSB16 + 256));
+    for (int pt = 0; pt < 4; ++pt) bb[pt] = tap_bb(tap, pt);
+    // cell 224: taps with dr <= 0 and dc <= 0 are on the board for that corner cell; the others read the zero row
+    const uint32_t lq = (uint32_t)(LCELL + (tap / 3 - 1) * N + (tap % 3 - 1));
+    lx32 = act32 + ((tap / 3 <= 1 && tap % 3 <= 1) ? ((lq << 8) | (((lq & 15u) ^ (uint32_t)kq) << 4)) : (uint32_t)(ZERO_OFF | (kq << 4)));
+  };
+  auto set_tap_B = [&](int tap) {
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt)
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fbA[pt]) : "v"(act32 + (bb[pt] ^ (uint32_t)((ks0 + i) << 6))));
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lw) : "v"(lw32), "i"(i * KSB16));
-      asm volatile("ds_read_b128 %0, %1" : "=v"(lx) : "v"(lx32 ^ (uint32_t)((ks0 + i) << 6)));
-    };
-    auto loadB = [&](int i) {  // 3 reads
+    for (int pt = 4; pt < 7; ++pt) bb[pt] = tap_bb(tap, pt);
+  };
+  f32x4 fbA[4], fbB[3], lx;
+  auto loadA = [&](int m) {  // 5 LDS reads: cell tiles 0..3 and the operand of cell 224
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt)
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fbB[pt]) : "v"(act32 + (bb[4 + pt] ^ (uint32_t)((ks0 + i) << 6))));
-    };
-    loadA(0);
+    for (int pt = 0; pt < 4; ++pt) asm volatile("ds_read_b128 %0, %1" : "=v"(fbA[pt]) : "v"(act32 + (bb[pt] ^ (uint32_t)(m << 6))));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(lx) : "v"(lx32 ^ (uint32_t)(m << 6)));
+  };
+  auto loadB = [&](int m) {  // 3 LDS reads: cell tiles 4..6
 #pragma unroll
-    for (int i = 0; i < KPSL; ++i) {
-      loadB(i);
-      asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");  // group A of k-step i has returned
+    for (int pt = 0; pt < 3; ++pt) asm volatile("ds_read_b128 %0, %1" : "=v"(fbB[pt]) : "v"(act32 + (bb[4 + pt] ^ (uint32_t)(m << 6))));
+  };
+  set_tap_A(0);
+  set_tap_B(0);
+  loadA(0);
+#pragma unroll 1
+  for (int kk = 0; kk < KSTEPS; kk += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = kk + u;
+      if (k >= KSTEPS) break;
+      const bool last = k + 1 >= KSTEPS;
+      // the next k-step's weights (the next layer's first, at the end): in flight under this k-step's 56 MFMAs
+      if (!last) wload(wf[(u + 1) & 1], wlane, llane, k + 1);
+      else if (wnext != nullptr) wload(wf[(u + 1) & 1], wnext + woff, wnext + loff, 0);
+      loadB(k % KS16);
+      asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");  // group A of this k-step has returned
       __builtin_amdgcn_sched_barrier(0);
       if (LEFT) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) lc = fmaf(lw[t], lx[t], lc);
+        for (int t = 0; t < 4; ++t) lc = fmaf(wf[u].l[t], lx[t], lc);
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-          acc[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i & 1][0][t], fbA[pt][t], acc[pt][0], 0, 0, 0);
-          acc[pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i & 1][1][t], fbA[pt][t], acc[pt][1], 0, 0, 0);
+          acc[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].a0[t], fbA[pt][t], acc[pt][0], 0, 0, 0);
+          acc[pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].a1[t], fbA[pt][t], acc[pt][1], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
-      if (i == 0) {  // the DMA of the next stage's weights: on its way under this stage's MFMAs
-        char *wn = wbuf + ((buf + sg + 1) & 1) * STAGE_BYTES;
-        if (sg < NSTAGE - 1) stage_w<SB>(wg + (size_t)(sg + 1) * SB, wn, wave, lane);
-        else if (wnext != nullptr) stage_w<NEXT_BYTES>(wnext, wn, wave, lane);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (i + 1 < KPSL) {
-        loadA(i + 1);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // group B of k-step i has returned
+      if (!last) {
+        if ((k + 1) % KS16 == 0) set_tap_A((k + 1) / KS16);
+        loadA((k + 1) % KS16);
+        asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");  // group B of this k-step has returned
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (!last && (k + 1) % KS16 == 0) set_tap_B((k + 1) / KS16);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt) {
-          acc[4 + pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i & 1][0][t], fbB[pt][t], acc[4 + pt][0], 0, 0, 0);
-          acc[4 + pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i & 1][1][t], fbB[pt][t], acc[4 + pt][1], 0, 0, 0);
+          acc[4 + pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].a0[t], fbB[pt][t], acc[4 + pt][0], 0, 0, 0);
+          acc[4 + pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].a1[t], fbB[pt][t], acc[4 + pt][1], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next stage has landed
-    __syncthreads();
   }
-  buf = (buf + NSTAGE) & 1;
 }
 
 __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restrict__ x, const uint32_t *__restrict__ ring,
@@ -477,21 +493,22 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
                                                           const float *__restrict__ headb, float *__restrict__ feat, int FS,
                                                           unsigned int *tickets) {
   constexpr int N = 15, NV = 225, WC = 8, SWB = 16, RGW = 8 * SWB, LCELL = 224, KP = 240;
-  constexpr int ACT_BYTES = NV * ROW + ROW, HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16, RG_BYTES = ((RGW + 3) * 4 + 15) / 16 * 16;
+  constexpr int ACT_BYTES = NV * ROW + ROW, HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16, RG_BYTES = ((RGW + 4) * 4 + 15) / 16 * 16;
   constexpr int KSB16 = 4 * C * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *act = smem;
-  char *wbuf = smem + ACT_BYTES;
-  float *hw = (float *)(wbuf + 2 * STAGE_BYTES);
+  float *hw = (float *)(smem + ACT_BYTES);
   uint32_t *rg = (uint32_t *)((char *)hw + HW_BYTES);  // RGW ring words, player, slot, ticket
-  int *slots = (int *)rg + RGW + 1;
-  float *hp = (float *)((char *)rg + RG_BYTES);         // [2 cell halves][7 tiles][16 cells][3]: head sums of the upper-channel waves
-  float *lh = hp + 2 * 7 * 16 * 3;                      // [4 waves][3]: head sums of cell 224
+  int *slots = (int *)rg + RGW + 1;   // {this board's slot, its ticket (G = past the end), the slot looked up ahead}
+  float *hp = (float *)((char *)rg + RG_BYTES);         // [2 channel halves][3 heads][225 cells]: partial head sums
+  float *lh = hp + 2 * 3 * NV + 2;                      // [4 waves][3]: head sums of cell 224
+  float *bl = lh + 12;                                  // [(1 + L)][64]: every layer's bias (L <= T16_MAX_LAYERS)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, ch = wave >> 1, chalf = wave & 1;
 
   for (int i = tid; i < ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero row
   for (int i = tid; i < 3 * C + 3; i += 256) hw[i] = i < 3 * C ? headw[i] : headb[i - 3 * C];
+  for (int i = tid; i < (1 + L) * C; i += 256) bl[i] = bias[i];
 
   const int pp0 = 7 * chalf * 16 + (lane & 15);  // this lane's cells: pp0 + 16 pt
   unsigned long long vm = 0;                      // bit 9 pt + tap: tap of that cell is on the board
@@ -504,29 +521,55 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
       if (rr >= 0 && rr < N && cc >= 0 && cc < N) vm |= 1ull << (9 * pt + t);
     }
   }
-  int buf = 0;
-  stage_w<KSB16>(w0, wbuf, wave, lane);  // the stem's first stage (one tap: 16 padded channels = one k-step)
-  int ticket = (int)blockIdx.x;
+  WFrag wf[2];  // weight fragments of the running and the next k-step (global -> registers, one k-step ahead)
+  wload(wf[0], w0 + kq * (C * 16) + (ch * 32 + (lane & 15)) * 16, w0 + kq * (C * 16) + (wave * 16 + (lane & 15)) * 16, 0);  // the stem's first
+  // Boards are handed out by the ticket counter.  The NEXT board is looked up while the current one is computed, in steps
+  // that are never waited for: the returning atomic is issued at the top of the board; after the stem thread 0 reads the
+  // ticket's flag byte; before the first block's barrier it publishes the slot (or -2: flagged off, look again at the
+  // top); after that barrier 129 threads request the slot's packed input into a register each.
+  int ticket = (int)blockIdx.x;   // thread 0: the next ticket
+  int pre_slot = -2;              // thread 0: the next board's slot if already known (-1: past the end, -2: not looked up)
+  uint8_t pre_flag = 0;
+  uint32_t pre_word = 0;          // threads < 129: word tid of the next board's packed input
+  bool pre_have = false;          // (uniform) pre_word holds the input of slots[2]
 
+#if AZ_F32_STAMP
+  int it = 0;
+  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (;;) {
+#if AZ_F32_STAMP
+    const bool stamp_on = blockIdx.x == 7 && it == 6;
+    ++it;
+#endif
+    FSTAMP(0);
     __syncthreads();
     if (tid == 0) {
-      for (;;) {
-        const bool on = ticket < G && (flags == nullptr || flags[ticket] != 0);
-        if (on || ticket >= G) break;
-        ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));  // a terminal leaf: one more draw
+      if (pre_slot == -2) {  // not looked up ahead (first board, or the ticket drawn ahead was a terminal leaf)
+        for (;;) {
+          const bool on = ticket < G && (flags == nullptr || flags[ticket] != 0);
+          if (on || ticket >= G) break;
+          ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));  // a terminal leaf: one more draw
+        }
+        pre_slot = ticket < G ? ticket : -1;
       }
-      slots[0] = ticket < G ? ticket : -1;
-      slots[1] = ticket;
+      slots[0] = pre_slot;
+      slots[1] = pre_slot < 0 ? G : pre_slot;
     }
     __syncthreads();
     if (slots[1] >= G) break;
+    FSTAMP(1);
     const int g = slots[0];
-    if (tid == 0) ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));
+    if (tid == 0) { ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u)); pre_slot = -2; }
     if (x == nullptr) {
-      for (int i = tid; i < RGW + 1; i += 256) rg[i] = i < RGW ? ring[(size_t)g * RGW + i] : (uint32_t)leafrec[g].w;
+      if (pre_have && slots[2] == g) {
+        if (tid < RGW + 1) rg[tid] = pre_word;
+      } else {
+        for (int i = tid; i < RGW + 1; i += 256) rg[i] = i < RGW ? ring[(size_t)g * RGW + i] : (uint32_t)leafrec[g].w;
+      }
       __syncthreads();
     }
+    pre_have = false;
     if (tid < NV) {
       const int cell = tid;
       float c[16];
@@ -546,8 +589,8 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
 #pragma unroll
       for (int k = 0; k < 4; ++k) *(f32x4 *)(act + act_addr(cell, k)) = (f32x4){c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]};
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    FSTAMP(2);
 
     f32x4 acc[7][2], res[7][2];
     float lc = 0.0f, lres = 0.0f;  // cell 224: output channel lco of this wave's 16, partial over this lane's k quarter
@@ -580,14 +623,18 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
       if (kq == 0) *lptr = fmaxf(lc, 0.0f);
     };
     // ---- stem
-    init(bias, false);
-    if (L > 0) conv_layer16<1, 1, 2 * KSB16, true>(act, wbuf, buf, w0, wl, wave, lane, pp0, vm, acc, lc);
-    else conv_layer16<1, 1, KSB16, true>(act, wbuf, buf, w0, w0, wave, lane, pp0, vm, acc, lc);
-    lfinal(bias, false);
+    init(bl, false);
+    conv_layer16g<9, 1, true>(act, w0, L > 0 ? wl : w0, wave, lane, pp0, vm, acc, lc, wf);  // (nine k-steps: the prefetch lands in wf[1])
+    lfinal(bl, false);
+    FSTAMP(3);
     if (L > 0) {
+      __syncthreads();  // every wave has read the layer's input: the outputs may overwrite it
       epilogue();
       __syncthreads();
     }
+    FSTAMP(4);
+    wf[0] = wf[1];
+    if (tid == 0 && ticket < G && flags != nullptr) pre_flag = flags[ticket];  // (consumed before the first block's barrier)
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
 #pragma unroll
@@ -595,22 +642,41 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) res[pt][ct] = *(const f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + ct) * 4 + kq));
       lres = *lptr;
-      init(bias + (1 + l) * C, false);
-      conv_layer16<4, 2, 2 * KSB16, true>(act, wbuf, buf, wl + (size_t)l * 9 * 4 * KSB16, wl + (size_t)(l + 1) * 9 * 4 * KSB16, wave, lane, pp0, vm,
-                                            acc, lc);
-      lfinal(bias + (1 + l) * C, false);
-      epilogue();
+      init(bl + (1 + l) * C, false);
+      FSTAMP(5 + 4 * l);
+      conv_layer16g<36, 4, true>(act, wl + (size_t)l * 9 * 4 * KSB16, wl + (size_t)(l + 1) * 9 * 4 * KSB16, wave, lane, pp0, vm, acc, lc, wf);
+      lfinal(bl + (1 + l) * C, false);
+      FSTAMP(6 + 4 * l);
+      if (l == 0 && tid == 0) {  // publish the next board's slot
+        pre_slot = ticket >= G ? -1 : ((flags == nullptr || pre_flag != 0) ? ticket : -2);
+        slots[2] = pre_slot;
+      }
       __syncthreads();
-      init(bias + (2 + l) * C, true);
+      FSTAMP(7 + 4 * l);
+      epilogue();
+      if (l == 0 && x == nullptr) {  // (slots[2] was written before the barrier above)
+        const int gn = slots[2];
+        pre_have = gn >= 0;
+        if (pre_have && tid < RGW + 1) pre_word = tid < RGW ? ring[(size_t)gn * RGW + tid] : (uint32_t)leafrec[gn].w;
+      }
+      __syncthreads();
+      FSTAMP(8 + 4 * l);
+      init(bl + (2 + l) * C, true);
+      FSTAMP(9 + 4 * l);
       if (l + 2 < L) {
-        conv_layer16<4, 2, 2 * KSB16, true>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * 4 * KSB16, wl + (size_t)(l + 2) * 9 * 4 * KSB16, wave, lane,
-                                              pp0, vm, acc, lc);
-        lfinal(bias + (2 + l) * C, true);
+        conv_layer16g<36, 4, true>(act, wl + (size_t)(l + 1) * 9 * 4 * KSB16, wl + (size_t)(l + 2) * 9 * 4 * KSB16, wave, lane, pp0, vm, acc, lc,
+                                   wf);
+        lfinal(bl + (2 + l) * C, true);
+        FSTAMP(10 + 4 * l);
+        __syncthreads();
+        FSTAMP(11 + 4 * l);
         epilogue();
         __syncthreads();
-      } else {
-        conv_layer16<4, 2, KSB16, true>(act, wbuf, buf, wl + (size_t)(l + 1) * 9 * 4 * KSB16, w0, wave, lane, pp0, vm, acc, lc);
-        lfinal(bias + (2 + l) * C, true);
+        FSTAMP(12 + 4 * l);
+      } else {  // the tower's last layer: its output stays in the accumulators for the heads; prefetch the next board's stem
+        conv_layer16g<36, 4, true>(act, wl + (size_t)(l + 1) * 9 * 4 * KSB16, w0, wave, lane, pp0, vm, acc, lc, wf);
+        lfinal(bl + (2 + l) * C, true);
+        FSTAMP(10 + 4 * l);
       }
     }
     // ---- heads: 1x1 convs + ReLU from the accumulators.  A lane holds 8 of its cell's channels (2 channel tiles x 4), the
@@ -633,6 +699,7 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
             for (int k = 0; k < 3; ++k) hs[pt][k] = fmaf(a, wv[k][j], hs[pt][k]);
           }
       }
+      FSTAMP(26);
 #pragma unroll
       for (int pt = 0; pt < 7; ++pt)
 #pragma unroll
@@ -642,6 +709,7 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
           t = t + __shfl_xor(t, 32, 64);
           hs[pt][k] = t;
         }
+      FSTAMP(27);
       {  // cell 224: this wave's 16 channels (lanes of k quarter 0), butterfly over those lanes, partial per wave to LDS
         const float a = kq == 0 ? fmaxf(lc, 0.0f) : 0.0f;
 #pragma unroll
@@ -652,32 +720,33 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
           if (lane == 0) lh[wave * 3 + k] = t;
         }
       }
-      if (ch == 1 && kq == 0) {
 #pragma unroll
-        for (int pt = 0; pt < 7; ++pt)
+      for (int pt = 0; pt < 7; ++pt) {
+        if ((pt & 3) != kq) continue;  // the four k-quarter groups share the LDS stores (every lane holds the sum)
 #pragma unroll
-          for (int k = 0; k < 3; ++k) hp[((chalf * 7 + pt) * 16 + (lane & 15)) * 3 + k] = hs[pt][k];
+        for (int k = 0; k < 3; ++k) hp[(ch * 3 + k) * NV + pp0 + 16 * pt] = hs[pt][k];
       }
+      FSTAMP(28);
       __syncthreads();
+      FSTAMP(29);
+      // the feature rows leave as whole-wave, consecutive 4-byte stores (a handful per wave: partial-wave scattered stores
+      // cost several hundred cycles of issue each)
       float *fr = feat + (size_t)g * FS;
-      if (ch == 0) {
-#pragma unroll
-        for (int pt = 0; pt < 7; ++pt) {
-          if ((pt & 3) != kq) continue;  // the four k-quarter groups share the stores
-          const int cell = (pp0 + 16 * pt);
-          const float *o = hp + ((chalf * 7 + pt) * 16 + (lane & 15)) * 3;
-          fr[cell] = fmaxf(hs[pt][0] + o[0] + hw[3 * C + 0], 0.0f);
-          fr[KP + cell] = fmaxf(hs[pt][1] + o[1] + hw[3 * C + 1], 0.0f);
-          fr[KP + NV + cell] = fmaxf(hs[pt][2] + o[2] + hw[3 * C + 2], 0.0f);
-        }
-      }
-      if (wave == 3 && lane < 3) {
-        const int k = lane;
-        const float t = ((lh[k] + lh[3 + k]) + lh[6 + k]) + lh[9 + k];
-        fr[(k == 0 ? 0 : KP + (k - 1) * NV) + LCELL] = fmaxf(t + hw[3 * C + k], 0.0f);
+      for (int e = tid; e < 3 * NV; e += 256) {
+        const int k = e / NV, cell = e - k * NV;
+        float v = cell == LCELL ? ((lh[k] + lh[3 + k]) + lh[6 + k]) + lh[9 + k] : hp[k * NV + cell] + hp[(3 + k) * NV + cell];
+        fr[(k == 0 ? 0 : KP + (k - 1) * NV) + cell] = fmaxf(v + hw[3 * C + k], 0.0f);
       }
     }
+    FSTAMP(30);
   }
+#if AZ_F32_STAMP
+  if (tid == 0) {
+    unsigned long long *o = g_f32_wg + 4 * blockIdx.x;
+    o[0] = wg_t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = (unsigned long long)(it - 1);
+    o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);
+  }
+#endif
   if (tid == 0 && atomicAdd(&tickets[1], 1u) == gridDim.x - 1) {
     tickets[0] = 0u;
     tickets[1] = 0u;
@@ -767,6 +836,15 @@ __global__ __launch_bounds__(256, 2) void k_heads_f32(const float *__restrict__ 
 static std::mutex g_f32_mutex;
 static unsigned int g_f32_attr_done[64];
 
+#if AZ_F32_STAMP
+extern "C" int az_debug_f32_stamps(unsigned long long *out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(aztf32::g_f32_stamps), sizeof(unsigned long long) * 4 * 32) == hipSuccess ? 0 : -3;
+}
+extern "C" int az_debug_f32_wg(unsigned long long *out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(aztf32::g_f32_wg), sizeof(unsigned long long) * 1024 * 4) == hipSuccess ? 0 : -3;
+}
+#endif
+
 extern "C" {
 
 int az_heads_forward_f32(int32_t board_size, int32_t n_boards, const float *feat_dev, int32_t feat_stride, const void *wp_dev,
@@ -823,7 +901,8 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
         g_f32_attr_done[dev] |= 1u << variant;
       }
     }
-    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * 2;  // two workgroups per CU
+    static const int wg_per_cu = getenv("AZ_TOWER_F32_WG1") ? 1 : 2;  // diagnostic: one workgroup per CU
+    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * wg_per_cu;  // two workgroups per CU
     const int grid = groups < cap ? groups : cap;
     const bool use_flags = !x_f32_dev && flags_dev;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, x_f32_dev, (const uint32_t *)packed_ring_dev, (const int4 *)packed_leaf_dev,
@@ -832,9 +911,9 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
     return AZ_OK;
   };
   int rc;
-  constexpr size_t LDS_T16 = (size_t)(225 * ROW + ROW) + 2 * STAGE_BYTES + ((3 * C + 3) * 4 + 15) / 16 * 16 + ((128 + 3) * 4 + 15) / 16 * 16 + 2 * 7 * 16 * 3 * 4 + 64;
+  constexpr size_t LDS_T16 = (size_t)(225 * ROW + ROW) + ((3 * C + 3) * 4 + 15) / 16 * 16 + ((128 + 4) * 4 + 15) / 16 * 16 + (2 * 3 * 225 + 2 + 12) * 4 + (1 + T16_MAX_LAYERS) * C * 4;
   static const bool use32 = getenv("AZ_TOWER_F32_TILE32") != nullptr;  // diagnostic: the 32-cell-tile kernel on 15x15 too
-  if (board_size == 15 && !use32) rc = launch(k_tower_f32_t16, LDS_T16, 1, 2);
+  if (board_size == 15 && !use32 && n_conv_layers <= T16_MAX_LAYERS) rc = launch(k_tower_f32_t16, LDS_T16, 1, 2);
   else if (board_size == 15) rc = launch(k_tower_f32<15, 1>, GeoF<15, 1>::lds_bytes(), 1, 0);
   else rc = launch(k_tower_f32<9, 3>, GeoF<9, 3>::lds_bytes(), 3, 1);
   if (rc != AZ_OK) return rc;
