@@ -113,6 +113,49 @@ class GomokuNet(DualHeadNet):
         return total
 
 
+class _QuickResBlock(nn.Module):
+    """nn_models/resnet_blocks.py:28-40: ``x + Sequential((conv, BN, ReLU) x layers)`` -- no activation after the sum."""
+
+    def __init__(self, channels: int, layers: int) -> None:
+        super().__init__()
+        mods: list[nn.Module] = []
+        for _ in range(layers):
+            mods += [nn.Conv2d(channels, channels, 3, padding=1), nn.BatchNorm2d(channels), nn.ReLU()]
+        self.model = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return x + self.model(x)
+
+
+class QuickNet(DualHeadNet):
+    """The reference's QuickModel (nn_models/quick_model.py:29-240, built from config/quick_model_config.py) for ANY board:
+    the reference hard-wires it to tic-tac-toe through GAME_STATE_DIM / NUM_ACTION (config/quick_model_config.py:7-10), so
+    "QuickModel scaled up" (BASELINE config 5) has no instance there.  Same layer sequence and parameter names as the
+    reference's defaults: transition conv3x3(C_in -> channels)+BN+ReLU, ``blocks`` residual blocks of ``layers`` x
+    (conv3x3, BN, ReLU) with the sum taken AFTER the last ReLU; policy head conv3x3(channels -> 2)+BN+ReLU, Linear(2HW -> 64),
+    ReLU, Linear(64 -> A); value head conv3x3(channels -> 1)+BN+ReLU, Linear(HW -> 64), ReLU, Linear(64 -> 1), tanh applied
+    in ``value_head`` (:131-133).  It runs through its own PyTorch-ROCm forward (the fused towers cover the GomokuModel
+    family: 1x1 head convs, sum before the last ReLU)."""
+
+    def __init__(self, board_size: int = 15, in_channels: int = HISTORY_LEN + 1, channels: int = 128, blocks: int = 1,
+                 layers: int = 5, n_action: int | None = None, features: int = 64) -> None:
+        super().__init__()
+        hw = board_size * board_size
+        a = n_action if n_action is not None else hw
+        self.board_size = board_size
+        self._shared_layers = nn.Sequential(nn.Conv2d(in_channels, channels, 3, padding=1), nn.BatchNorm2d(channels), nn.ReLU(),
+                                            *[_QuickResBlock(channels, layers) for _ in range(blocks)])
+        self._policy_head = nn.Sequential(nn.Conv2d(channels, 2, 3, padding=1), nn.BatchNorm2d(2), nn.ReLU(), nn.Flatten(1),
+                                          nn.Linear(2 * hw, features), nn.ReLU(), nn.Linear(features, a))
+        self._value_head = nn.Sequential(nn.Conv2d(channels, 1, 3, padding=1), nn.BatchNorm2d(1), nn.ReLU(), nn.Flatten(1),
+                                         nn.Linear(hw, features), nn.ReLU(), nn.Linear(features, 1))
+
+    def value_head(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.tanh(self._value_head(x))
+
+    flops_per_eval = GomokuNet.flops_per_eval
+
+
 def flat_parameters(model: nn.Module) -> list[torch.Tensor]:
     """parameters + buffers in state_dict order: what a weight publish has to move
     (training/alphazero_trainer.py:53-66 moves the whole state_dict)."""

@@ -524,8 +524,46 @@ def make_loss():
     np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
 
 
+# --------------------------------------------------------------------------- QuickModel KAT --------
+def formula_weights(state_dict):
+    """deterministic weights from a closed formula (so the fixture need not carry 3 MB of floats): the test fills
+    alphazero_amd.nets.QuickNet with the same formula"""
+    out = {}
+    for i, (k, v) in enumerate(state_dict.items()):
+        n = v.numel()
+        idx = torch.arange(n, dtype=torch.float64)
+        if k.endswith("running_var"):
+            t = 0.5 + 0.5 * torch.sin(0.37 * idx + i) ** 2
+        elif k.endswith("num_batches_tracked"):
+            out[k] = v.clone()
+            continue
+        else:
+            t = 0.08 * torch.sin(0.11 * idx * (1 + (i % 7)) + 0.5 * i)
+        out[k] = t.to(torch.float32).view_as(v)
+    return out
+
+
+def make_quick():
+    """nn_models/quick_model.py QuickModel (default config: 3x3 board, 128 channels, one 5-layer residual block) forward
+    on fixed inputs with formula weights: parameter names, shapes and outputs."""
+    from nn_models.quick_model import QuickModel
+
+    m = QuickModel().eval()
+    m.load_state_dict(formula_weights(m.state_dict()))
+    rng = np.random.default_rng(3)
+    x = rng.integers(-1, 2, size=(6, 9, 3, 3)).astype(np.float32)
+    with torch.no_grad():
+        p, v = m(torch.from_numpy(x))
+    np.savez_compressed(os.path.join(OUT, "quick.npz"), names=np.array(list(m.state_dict().keys())),
+                        shapes=np.array([str(tuple(t.shape)) for t in m.state_dict().values()]),
+                        x=x.astype(np.int8), logits=p.numpy(), value=v.numpy())
+    print("quick", p.shape, v.shape)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "search", "selfplay", "augment", "loss"]
+    which = sys.argv[1:] or ["rules", "search", "selfplay", "augment", "loss", "quick"]
+    if "quick" in which:
+        make_quick()
     if "loss" in which:
         make_loss()
     if "rules" in which:

@@ -365,3 +365,41 @@ def test_bulk_writer_fills_the_reference_ring_like_its_own_puts(name, game, n, A
     for f in ("_write_idx", "_read_idx", "_size", "_total_written"):
         assert getattr(got, f).value == getattr(want, f).value, f
     assert torch.equal(got._states, want._states) and torch.equal(got._prior, want._prior) and torch.equal(got._values, want._values)
+
+
+@pytest.mark.parametrize("kind", ["gomokunet-128x4-fused-bf16", "quicknet-128x2x3-pytorch-f32"])
+def test_config5_shape_self_play_train_loop(kind):
+    """BASELINE config 5 at its real board and width (gomoku 15x15, 128 channels, >= 4 residual conv pairs), a few moves of
+    the self-play + training loop: the GomokuNet-family tower on the fused bf16 kernel, and the reference's QuickModel
+    architecture (nets.QuickNet, 'quick_model scaled up') through its own PyTorch forward in f32."""
+    from alphazero_amd.loop import SelfPlayTrainLoop
+    from alphazero_amd.nets import GomokuNet, QuickNet
+
+    torch.manual_seed(0)
+    if kind.startswith("gomokunet"):
+        net, dt = GomokuNet(15, 128, 4), torch.bfloat16
+    else:
+        net, dt = QuickNet(15, 9, 128, 2, 3), torch.float32
+    loop = SelfPlayTrainLoop(net, 2, 15, 48, 12, torch.device("cuda:0"), ring_capacity=1 << 13, batch_size=64,
+                             train_steps_per_move=1, min_samples=256, publish_every=2, nn_dtype=dt)
+    assert (loop.runner.fused is not None) == kind.startswith("gomokunet")
+    # a trained-looking value head ends games early; with random weights games run long, so force short games: play
+    # until some finish (12 simulations per move, 48 games)
+    out = loop.run(14)
+    st = loop.engine.read_stats()
+    assert st["sims"] == 48 * 12 * 14 and out["moves"] == 14
+    # feed the ring by hand from the positions played so far if no game has ended yet (five in a row needs >= 9 plies)
+    if loop.ring.size() < 256:
+        plies, _, active, _ = loop.engine.game_info()
+        assert int(plies.min()) >= 1
+        d = loop.engine.dims
+        s = loop.engine.root_nn_state().reshape(48, -1)
+        pi = loop.engine.root_policy()
+        loop.ring.put_games(s, torch.softmax(torch.randn(48, d.n_action, device="cuda"), 1), torch.zeros(48, device="cuda"))
+    before = [p.detach().clone() for p in loop.master.parameters()]
+    loss = [loop.learner.step(loop.ring, 64)[0] for _ in range(3)]
+    assert all(np.isfinite(loss))
+    assert any(not torch.equal(a, b) for a, b in zip(before, loop.master.parameters()))
+    loop._refresh_player()
+    loop.runner.move_round(loop.inv_tao)  # the refreshed network (re-folded tower) still searches
+    loop.engine.check()

@@ -354,3 +354,29 @@ def test_learner_loss_and_step_match_reference_golden(tag):
         a = v.detach().numpy().reshape(-1)
         np.testing.assert_allclose(a[:16], z[f"{tag}__after_head__{k}"], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(a.astype(np.float64).sum(), float(z[f"{tag}__after_sum__{k}"]), rtol=1e-5, atol=1e-5)
+
+
+def test_quicknet_is_the_reference_quickmodel():
+    """alphazero_amd.nets.QuickNet at the reference's default configuration (3x3 board, 128 channels, one residual block of
+    five conv layers) == nn_models/quick_model.py QuickModel: same parameter names and shapes, same outputs on recorded
+    inputs with formula weights (tests/golden/quick.npz, written by make_golden.py from the reference)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden_formula", os.path.join(GOLDEN, "make_golden.py"))
+    src = open(spec.origin).read()
+    ns = {"torch": torch}
+    start = src.index("def formula_weights")
+    exec(src[start:src.index("def make_quick")], ns)  # the formula only (the rest of that script imports the reference)
+    z = np.load(os.path.join(GOLDEN, "quick.npz"))
+    net = nets.QuickNet(3, 9, 128, 1, 5, 9, 64).eval()
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z["names"]]
+    assert [str(tuple(t.shape)) for t in sd.values()] == [str(s) for s in z["shapes"]]
+    net.load_state_dict(ns["formula_weights"](sd))
+    with torch.no_grad():
+        p, v = net(torch.from_numpy(z["x"].astype(np.float32)))
+    np.testing.assert_allclose(p.numpy(), z["logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v.numpy(), z["value"], rtol=1e-5, atol=1e-6)
+    big = nets.QuickNet(15, 9, 128, 4, 5)  # "scaled up" for gomoku 15x15 (BASELINE config 5)
+    p, v = big.eval()(torch.zeros(2, 9, 15, 15))
+    assert p.shape == (2, 225) and v.shape == (2, 1)
