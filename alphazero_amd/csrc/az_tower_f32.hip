@@ -393,27 +393,29 @@ constexpr int T16_MAX_LAYERS = 40;  // bias rows the 16-cell-tile kernel keeps i
 // launch (the partner wave of the SIMD does not reliably cover them).
 struct WFrag { f32x4 a0, a1, l; };  // a lane's weights of one k-step: both channel tiles + its row for cell 224
 
+template <int CW>
 __device__ __forceinline__ void wload(WFrag &w, const char *wlane, const char *llane, int kk) {
-  w.a0 = *(const f32x4 *)(wlane + (size_t)kk * 4096);
-  w.a1 = *(const f32x4 *)(wlane + (size_t)kk * 4096 + 256);
-  w.l = *(const f32x4 *)(llane + (size_t)kk * 4096);
+  constexpr int KSBW = 4 * CW * 16;  // bytes of one k-step of 16 input channels: [kq 4][co CW][4] f32
+  w.a0 = *(const f32x4 *)(wlane + (size_t)kk * KSBW);
+  w.a1 = *(const f32x4 *)(wlane + (size_t)kk * KSBW + 256);
+  w.l = *(const f32x4 *)(llane + (size_t)kk * KSBW);
 }
 
 // On entry wf[0] holds (or is about to receive) k-step 0 of this layer; the weights of wnext's k-step 0 are requested
 // during the last k-step, into wf[KSTEPS & 1].  KS16 = k-steps per tap.  No barrier inside: the caller synchronises.
-template <int KSTEPS, int KS16, bool LEFT>
+template <int KSTEPS, int KS16, bool LEFT, int CW>
 __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, const char *wnext, int wave, int lane, const int pp0,
                                               const unsigned long long vm, f32x4 (&acc)[7][2], float &lc, WFrag (&wf)[2]) {
-  constexpr int N = 15, ZERO_OFF = 225 * ROW, LCELL = 224;
+  constexpr int N = 15, ROWW = 4 * CW, ZERO_OFF = 225 * ROWW, LCELL = 224;
   const int kq = lane >> 4, r = lane & 15, ch = wave >> 1;
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
-  const int woff = kq * (C * 16) + (ch * 32 + r) * 16, loff = kq * (C * 16) + (wave * 16 + r) * 16;
+  const int woff = kq * (CW * 16) + (ch * 32 + r) * 16, loff = kq * (CW * 16) + (wave * 16 + r) * 16;
   const char *wlane = wg + woff, *llane = wg + loff;
   uint32_t bb[7], lx32 = 0;
   auto tap_bb = [&](int tap, int pt) -> uint32_t {  // (the lane's cells are pp0 + 16 pt; bit 9 pt + tap of vm: that tap is on the board)
     const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
     const uint32_t q = (uint32_t)(pp0 + 16 * pt + d);
-    const uint32_t in = (q << 8) | (((q & 15u) ^ (uint32_t)kq) << 4);
+    const uint32_t in = (q * ROWW) | (((q & 15u) ^ (uint32_t)kq) << 4);
     return ((vm >> (9 * pt + tap)) & 1ull) ? in : (uint32_t)(ZERO_OFF | (kq << 4));
   };
   auto set_tap_A = [&](int tap) {
@@ -421,7 +423,7 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
     for (int pt = 0; pt < 4; ++pt) bb[pt] = tap_bb(tap, pt);
     // cell 224: taps with dr <= 0 and dc <= 0 are on the board for that corner cell; the others read the zero row
     const uint32_t lq = (uint32_t)(LCELL + (tap / 3 - 1) * N + (tap % 3 - 1));
-    lx32 = act32 + ((tap / 3 <= 1 && tap % 3 <= 1) ? ((lq << 8) | (((lq & 15u) ^ (uint32_t)kq) << 4)) : (uint32_t)(ZERO_OFF | (kq << 4)));
+    lx32 = act32 + ((tap / 3 <= 1 && tap % 3 <= 1) ? ((lq * ROWW) | (((lq & 15u) ^ (uint32_t)kq) << 4)) : (uint32_t)(ZERO_OFF | (kq << 4)));
   };
   auto set_tap_B = [&](int tap) {
 #pragma unroll
@@ -448,8 +450,8 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
       if (k >= KSTEPS) break;
       const bool last = k + 1 >= KSTEPS;
       // the next k-step's weights (the next layer's first, at the end): in flight under this k-step's 56 MFMAs
-      if (!last) wload(wf[(u + 1) & 1], wlane, llane, k + 1);
-      else if (wnext != nullptr) wload(wf[(u + 1) & 1], wnext + woff, wnext + loff, 0);
+      if (!last) wload<CW>(wf[(u + 1) & 1], wlane, llane, k + 1);
+      else if (wnext != nullptr) wload<CW>(wf[(u + 1) & 1], wnext + woff, wnext + loff, 0);
       loadB(k % KS16);
       asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");  // group A of this k-step has returned
       __builtin_amdgcn_sched_barrier(0);
@@ -486,13 +488,15 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restrict__ x, const uint32_t *__restrict__ ring,
+template <int CW>
+__global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__restrict__ x, const uint32_t *__restrict__ ring,
                                                           const int4 *__restrict__ leafrec, const uint8_t *__restrict__ flags, int G,
                                                           const char *__restrict__ w0, const char *__restrict__ wl,
                                                           const float *__restrict__ bias, int L, const float *__restrict__ headw,
                                                           const float *__restrict__ headb, float *__restrict__ feat, int FS,
                                                           unsigned int *tickets) {
   constexpr int N = 15, NV = 225, WC = 8, SWB = 16, RGW = 8 * SWB, LCELL = 224, KP = 240;
+  constexpr int C = CW, ROW = 4 * CW, NW = CW / 16, NTH = 64 * NW, NCQ = CW / 32;  // waves; channel groups of 32
   constexpr int ACT_BYTES = NV * ROW + ROW, HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16, RG_BYTES = ((RGW + 4) * 4 + 15) / 16 * 16;
   constexpr int KSB16 = 4 * C * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -500,15 +504,16 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
   float *hw = (float *)(smem + ACT_BYTES);
   uint32_t *rg = (uint32_t *)((char *)hw + HW_BYTES);  // RGW ring words, player, slot, ticket
   int *slots = (int *)rg + RGW + 1;   // {this board's slot, its ticket (G = past the end), the slot looked up ahead}
-  float *hp = (float *)((char *)rg + RG_BYTES);         // [2 channel halves][3 heads][225 cells]: partial head sums
-  float *lh = hp + 2 * 3 * NV + 2;                      // [4 waves][3]: head sums of cell 224
-  float *bl = lh + 12;                                  // [(1 + L)][64]: every layer's bias (L <= T16_MAX_LAYERS)
+  float *hp = (float *)((char *)rg + RG_BYTES);         // [NCQ channel groups][3 heads][225 cells]: partial head sums
+  float *lh = hp + NCQ * 3 * NV + 2;                    // [NW waves][3]: head sums of cell 224
+  float *bl = lh + 3 * NW;                                  // [(1 + L)][64]: every layer's bias (L <= T16_MAX_LAYERS)
+  auto act_addr = [](int p, int chunk) { return p * (4 * CW) + ((chunk ^ (p & 15)) << 4); };
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, ch = wave >> 1, chalf = wave & 1;
 
-  for (int i = tid; i < ACT_BYTES / 16; i += 256) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero row
-  for (int i = tid; i < 3 * C + 3; i += 256) hw[i] = i < 3 * C ? headw[i] : headb[i - 3 * C];
-  for (int i = tid; i < (1 + L) * C; i += 256) bl[i] = bias[i];
+  for (int i = tid; i < ACT_BYTES / 16; i += NTH) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero row
+  for (int i = tid; i < 3 * C + 3; i += NTH) hw[i] = i < 3 * C ? headw[i] : headb[i - 3 * C];
+  for (int i = tid; i < (1 + L) * C; i += NTH) bl[i] = bias[i];
 
   const int pp0 = 7 * chalf * 16 + (lane & 15);  // this lane's cells: pp0 + 16 pt
   unsigned long long vm = 0;                      // bit 9 pt + tap: tap of that cell is on the board
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
     }
   }
   WFrag wf[2];  // weight fragments of the running and the next k-step (global -> registers, one k-step ahead)
-  wload(wf[0], w0 + kq * (C * 16) + (ch * 32 + (lane & 15)) * 16, w0 + kq * (C * 16) + (wave * 16 + (lane & 15)) * 16, 0);  // the stem's first
+  wload<CW>(wf[0], w0 + kq * (C * 16) + (ch * 32 + (lane & 15)) * 16, w0 + kq * (C * 16) + (wave * 16 + (lane & 15)) * 16, 0);  // the stem's first
   // Boards are handed out by the ticket counter.  The NEXT board is looked up while the current one is computed, in steps
   // that are never waited for: the returning atomic is issued at the top of the board; after the stem thread 0 reads the
   // ticket's flag byte; before the first block's barrier it publishes the slot (or -2: flagged off, look again at the
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
       if (pre_have && slots[2] == g) {
         if (tid < RGW + 1) rg[tid] = pre_word;
       } else {
-        for (int i = tid; i < RGW + 1; i += 256) rg[i] = i < RGW ? ring[(size_t)g * RGW + i] : (uint32_t)leafrec[g].w;
+        for (int i = tid; i < RGW + 1; i += NTH) rg[i] = i < RGW ? ring[(size_t)g * RGW + i] : (uint32_t)leafrec[g].w;
       }
       __syncthreads();
     }
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
     };
     // ---- stem
     init(bl, false);
-    conv_layer16g<9, 1, true>(act, w0, L > 0 ? wl : w0, wave, lane, pp0, vm, acc, lc, wf);  // (nine k-steps: the prefetch lands in wf[1])
+    conv_layer16g<9, 1, true, CW>(act, w0, L > 0 ? wl : w0, wave, lane, pp0, vm, acc, lc, wf);  // (nine k-steps: the prefetch lands in wf[1])
     lfinal(bl, false);
     FSTAMP(3);
     if (L > 0) {
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
       lres = *lptr;
       init(bl + (1 + l) * C, false);
       FSTAMP(5 + 4 * l);
-      conv_layer16g<36, 4, true>(act, wl + (size_t)l * 9 * 4 * KSB16, wl + (size_t)(l + 1) * 9 * 4 * KSB16, wave, lane, pp0, vm, acc, lc, wf);
+      conv_layer16g<9 * (CW / 16), CW / 16, true, CW>(act, wl + (size_t)l * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc, wf);
       lfinal(bl + (1 + l) * C, false);
       FSTAMP(6 + 4 * l);
       if (l == 0 && tid == 0) {  // publish the next board's slot
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
       init(bl + (2 + l) * C, true);
       FSTAMP(9 + 4 * l);
       if (l + 2 < L) {
-        conv_layer16g<36, 4, true>(act, wl + (size_t)(l + 1) * 9 * 4 * KSB16, wl + (size_t)(l + 2) * 9 * 4 * KSB16, wave, lane, pp0, vm, acc, lc,
+        conv_layer16g<9 * (CW / 16), CW / 16, true, CW>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 2) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc,
                                    wf);
         lfinal(bl + (2 + l) * C, true);
         FSTAMP(10 + 4 * l);
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
         __syncthreads();
         FSTAMP(12 + 4 * l);
       } else {  // the tower's last layer: its output stays in the accumulators for the heads; prefetch the next board's stem
-        conv_layer16g<36, 4, true>(act, wl + (size_t)(l + 1) * 9 * 4 * KSB16, w0, wave, lane, pp0, vm, acc, lc, wf);
+        conv_layer16g<9 * (CW / 16), CW / 16, true, CW>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, w0, wave, lane, pp0, vm, acc, lc, wf);
         lfinal(bl + (2 + l) * C, true);
         FSTAMP(10 + 4 * l);
       }
@@ -732,9 +737,16 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32_t16(const float *__restric
       // the feature rows leave as whole-wave, consecutive 4-byte stores (a handful per wave: partial-wave scattered stores
       // cost several hundred cycles of issue each)
       float *fr = feat + (size_t)g * FS;
-      for (int e = tid; e < 3 * NV; e += 256) {
+      for (int e = tid; e < 3 * NV; e += NTH) {
         const int k = e / NV, cell = e - k * NV;
-        float v = cell == LCELL ? ((lh[k] + lh[3 + k]) + lh[6 + k]) + lh[9 + k] : hp[k * NV + cell] + hp[(3 + k) * NV + cell];
+        float v = 0.0f;
+        if (cell == LCELL) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) v += lh[3 * w + k];
+        } else {
+#pragma unroll
+          for (int c = 0; c < NCQ; ++c) v += hp[(3 * c + k) * NV + cell];
+        }
         fr[(k == 0 ? 0 : KP + (k - 1) * NV) + cell] = fmaxf(v + hw[3 * C + k], 0.0f);
       }
     }
@@ -876,7 +888,11 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
   if ((!x_f32_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !feat_f32_dev ||
       (n_conv_layers > 0 && !wl_dev)) { tower_set_error("null argument"); return AZ_EINVAL; }
   if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1)) { tower_set_error("n_boards >= 1, even n_conv_layers"); return AZ_EINVAL; }
-  if ((board_size != 9 && board_size != 15) || channels != 64) { tower_set_error("f32 tower: board_size 9 or 15, 64 channels"); return AZ_EINVAL; }
+  if ((board_size != 9 && board_size != 15) || (channels != 64 && !(channels == 128 && board_size == 15))) {
+    tower_set_error("f32 tower: board_size 9 or 15 with 64 channels, or 15 with 128 channels");
+    return AZ_EINVAL;
+  }
+  if (channels == 128 && n_conv_layers > T16_MAX_LAYERS) { tower_set_error("f32 tower, 128 channels: at most 40 conv layers"); return AZ_EINVAL; }
   if (feat_stride < az_heads_feat_stride(board_size)) { tower_set_error("feat_stride below az_heads_feat_stride(board_size)"); return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   int dev = 0, cur = 0;
@@ -889,8 +905,8 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
   } guard(dev, cur);
   unsigned int *tickets = tower_tickets(dev, s);
   if (tickets == nullptr) return AZ_EHIP;
-  auto launch = [&](auto kern, size_t lds, int bpw, int variant) -> int {
-    if (lds * 2 > 160 * 1024) { tower_set_error("f32 tower geometry exceeds the CU's LDS"); return AZ_EINVAL; }
+  auto launch = [&](auto kern, size_t lds, int bpw, int variant, int wg_cu = 2, int threads = 256) -> int {
+    if (lds * wg_cu > 160 * 1024) { tower_set_error("f32 tower geometry exceeds the CU's LDS"); return AZ_EINVAL; }
     {
       std::lock_guard<std::mutex> lock(g_f32_mutex);
       if (!(g_f32_attr_done[dev] & (1u << variant))) {
@@ -902,18 +918,22 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
       }
     }
     static const int wg_per_cu = getenv("AZ_TOWER_F32_WG1") ? 1 : 2;  // diagnostic: one workgroup per CU
-    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * wg_per_cu;  // two workgroups per CU
+    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * (wg_per_cu < wg_cu ? wg_per_cu : wg_cu);  // workgroups that fit the chip
     const int grid = groups < cap ? groups : cap;
     const bool use_flags = !x_f32_dev && flags_dev;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, x_f32_dev, (const uint32_t *)packed_ring_dev, (const int4 *)packed_leaf_dev,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, x_f32_dev, (const uint32_t *)packed_ring_dev, (const int4 *)packed_leaf_dev,
                        (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
                        n_conv_layers, headw_dev, headb_dev, feat_f32_dev, (int)feat_stride, tickets);
     return AZ_OK;
   };
   int rc;
-  constexpr size_t LDS_T16 = (size_t)(225 * ROW + ROW) + ((3 * C + 3) * 4 + 15) / 16 * 16 + ((128 + 4) * 4 + 15) / 16 * 16 + (2 * 3 * 225 + 2 + 12) * 4 + (1 + T16_MAX_LAYERS) * C * 4;
+  auto lds_t16 = [](int cw) -> size_t {  // act + zero row, head filters, packed input, head partial sums, bias table
+    return (size_t)(226 * 4 * cw) + ((3 * cw + 3) * 4 + 15) / 16 * 16 + ((128 + 4) * 4 + 15) / 16 * 16 + ((cw / 32) * 3 * 225 + 2 + 3 * (cw / 16)) * 4 +
+           (size_t)(1 + T16_MAX_LAYERS) * cw * 4;
+  };
   static const bool use32 = getenv("AZ_TOWER_F32_TILE32") != nullptr;  // diagnostic: the 32-cell-tile kernel on 15x15 too
-  if (board_size == 15 && !use32 && n_conv_layers <= T16_MAX_LAYERS) rc = launch(k_tower_f32_t16, LDS_T16, 1, 2);
+  if (channels == 128) rc = launch(k_tower_f32_t16<128>, lds_t16(128), 1, 3, 1, 512);
+  else if (board_size == 15 && !use32 && n_conv_layers <= T16_MAX_LAYERS) rc = launch(k_tower_f32_t16<64>, lds_t16(64), 1, 2);
   else if (board_size == 15) rc = launch(k_tower_f32<15, 1>, GeoF<15, 1>::lds_bytes(), 1, 0);
   else rc = launch(k_tower_f32<9, 3>, GeoF<9, 3>::lds_bytes(), 3, 1);
   if (rc != AZ_OK) return rc;

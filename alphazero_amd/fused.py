@@ -95,8 +95,8 @@ class FusedTowerEvaluator:
         self.ch = model._shared_layers[0].out_channels
         if precision not in ("bf16", "f32"):
             raise EngineError("FusedTowerEvaluator: precision must be 'bf16' or 'f32'")
-        if precision == "f32" and self.ch != 64:
-            raise EngineError("FusedTowerEvaluator: the f32 tower exists for 64-channel trunks")
+        if precision == "f32" and not (self.ch == 64 or (self.ch == 128 and self.board == 15)):
+            raise EngineError("FusedTowerEvaluator: the f32 tower exists for 64-channel trunks (9x9, 15x15) and 128-channel 15x15 trunks")
         self.precision = precision
         self.in_dtype = torch.float32 if precision == "f32" else torch.bfloat16
         self._buf = {}

@@ -153,7 +153,9 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     if evaluator == "auto":
         from alphazero_amd.fused import FusedTowerEvaluator
 
-        ok = FusedTowerEvaluator.supports(model) and (tdtype == torch.bfloat16 or (tdtype == torch.float32 and WORKLOADS[args.workload][4].get("channels") == 64))
+        kw_ = WORKLOADS[args.workload][4]
+        f32_ok = kw_.get("channels") == 64 or (kw_.get("channels") == 128 and kw_.get("board_size") == 15)
+        ok = FusedTowerEvaluator.supports(model) and (tdtype == torch.bfloat16 or (tdtype == torch.float32 and f32_ok))
         evaluator = "fused" if ok else "model"
     run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))
     if evaluator == "hash":  # tree kernels alone (no network)
@@ -533,9 +535,8 @@ def main():
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--sims", type=int, default=0)
     ap.add_argument("--dtype", default="auto", choices=["auto", "bf16", "f16", "f32"],
-                    help="network arithmetic of the PRIMARY line.  auto = f32, the reference's own precision (nn_models/base.py:17-19), "
-                         "wherever the f32 tower exists (64-channel gomoku nets) or the module's PyTorch forward is used; bf16 for the "
-                         "128-channel config-5 tower")
+                    help="network arithmetic of the PRIMARY line.  auto = f32, the reference's own precision (nn_models/base.py:17-19): the "
+                         "hand-written f32 tower for the GomokuModel family, the module's own PyTorch forward otherwise")
     ap.add_argument("--secondary-steps", type=int, default=-1, help="timed steps of the second line at the other precision (bf16 "
                     "throughput mode beside an f32 primary), reported as the object 'throughput_mode'; -1 = min(steps, 4) at one GPU, 0 = skip")
     ap.add_argument("--evaluator", default="auto", choices=["auto", "fused", "model", "hash"],
@@ -581,7 +582,7 @@ def main():
     kw = WORKLOADS[args.workload][4]
     primary = args.dtype
     if primary == "auto":
-        primary = "bf16" if (kw.get("channels", 64) != 64 and args.evaluator in ("auto", "fused")) else "f32"
+        primary = "f32"  # the reference's own arithmetic; every workload has an f32 evaluator (hand-written tower or the module's forward)
     out = measure(args, primary, args.steps, args.warmup, dev, rank, world, use_dist)
     sec_steps = args.secondary_steps if args.secondary_steps >= 0 else (min(args.steps, 4) if world == 1 else 0)
     second = None

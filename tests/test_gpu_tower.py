@@ -50,9 +50,10 @@ def test_fused_tower_matches_fp32_forward(board, blocks, batch, ch):
     assert float((p - ref_p).abs().mean()) <= 1.5 * float((bp.float() - ref_p).abs().mean()) + 1e-4
 
 
-@pytest.mark.parametrize("board,blocks,batch", [(15, 2, 64), (15, 2, 1100), (15, 3, 33), (9, 2, 100), (9, 1, 7), (15, 0, 5), (9, 0, 4),
-                                                (15, 10, 600), (9, 6, 50)])
-def test_f32_tower_matches_fp32_forward(board, blocks, batch):
+@pytest.mark.parametrize("board,blocks,batch,ch", [(15, 2, 64, 64), (15, 2, 1100, 64), (15, 3, 33, 64), (9, 2, 100, 64), (9, 1, 7, 64),
+                                                   (15, 0, 5, 64), (9, 0, 4, 64), (15, 10, 600, 64), (9, 6, 50, 64),
+                                                   (15, 2, 300, 128), (15, 10, 270, 128), (15, 0, 9, 128)])
+def test_f32_tower_matches_fp32_forward(board, blocks, batch, ch):
     """az_tower_f32.hip: f32 operands, f32 accumulation -- the reference's own arithmetic (nn_models/base.py:17-19).  Bar
     (north_star: priors within 1e-5 relative): logits within 2e-5 of the logit scale of PyTorch's f32 forward (which differs
     from any other f32 implementation by summation order and by BatchNorm applied after the conv rather than folded)."""
@@ -60,7 +61,7 @@ def test_f32_tower_matches_fp32_forward(board, blocks, batch):
     from alphazero_amd.nets import GomokuNet
 
     torch.manual_seed(0)
-    net = _randomised(GomokuNet(board, 64, blocks)).eval().cuda()
+    net = _randomised(GomokuNet(board, ch, blocks)).eval().cuda()
     ev = FusedTowerEvaluator(net, "f32")
     x = torch.randint(-1, 2, (batch, 9, board, board), device="cuda").float()
     x[:, 8] = torch.where(torch.rand(batch, 1, 1, device="cuda") < 0.5, -1.0, 1.0)
@@ -88,9 +89,9 @@ def test_f32_tower_packed_leaf_batch_equals_dense_planes():
     from alphazero_amd.nets import GomokuNet
 
     torch.manual_seed(0)
-    for board, G in ((15, 1300), (9, 700)):
+    for board, G, ch in ((15, 1300, 64), (9, 700, 64), (15, 600, 128)):
         sims = 10
-        ev = FusedTowerEvaluator(_randomised(GomokuNet(board, 64, 2)).eval().cuda(), "f32")
+        ev = FusedTowerEvaluator(_randomised(GomokuNet(board, ch, 2)).eval().cuda(), "f32")
         eng = Engine(2, G, sims, board_size=board, nn_dtype=torch.float32, device="cuda:0")
         nn = eng.new_nn_input()
         A = board * board
