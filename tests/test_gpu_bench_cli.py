@@ -1,0 +1,47 @@
+"""bench.py end to end at toy sizes: the JSON contract (metric / value / roofline / cpu_baseline / throughput_mode) and the
+torch.distributed path (RCCL barrier, all-reduce of the timings, weight broadcast) with one rank under --force-dist."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from .conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--preroll", "4", "--game-probe", "16",
+           "--cpu-baseline-seconds", "1", *extra]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_line_gomoku_f32_primary_with_bf16_beside_it_under_rccl():
+    d = _run(["--workload", "gomoku9", "--slots", "256", "--sims", "24", "--force-dist"])
+    assert d["metric"] == "mcts_sims_per_sec" and d["unit"] == "sims/s" and d["n_gpus"] == 1 and d["dtype"] == "f32"
+    assert d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["kernel"] == "k_tower_f32" and r["peak"] == 157.3 and 0 < r["frac"] < 1
+    assert d["roofline_tree"]["bound"] == "hbm" and d["roofline_tree"]["peak"] == 8000.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    t = d["throughput_mode"]
+    assert t["dtype"] == "bf16" and t["roofline"]["kernel"] == "k_tower" and t["roofline"]["peak"] == 2500.0
+    a = t["decision_agreement"]
+    assert 0.5 <= a["same_most_visited_move"] <= 1.0 and a["positions"] > 0
+
+
+def test_bench_line_small_game_through_pytorch():
+    d = _run(["--workload", "dab", "--slots", "128", "--sims", "16", "--graph", "1", "--no-cpu-baseline"])
+    assert d["dtype"] == "f32" and d["value"] > 0 and d["cpu_baseline"] is None and "throughput_mode" not in d
+    assert d["roofline"]["kernel"] == "k_expand_select"  # no fused evaluator for this net: the tree kernel's HBM roofline
