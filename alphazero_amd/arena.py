@@ -80,15 +80,20 @@ class SelfPlayRunner:
         self.model_dtype = p.dtype if p is not None else torch.float32
         self.use_graph, self._graph = use_graph, None
         self.fused = None
-        if fused:  # hand-written MFMA conv tower (csrc/az_tower.hip) instead of the module's own forward
-            from .fused import FusedTowerEvaluator
+        if fused:  # hand-written MFMA network kernels (csrc/az_tower*.hip, csrc/az_smallnet.hip) instead of the module's own forward
+            from .fused import FusedTowerEvaluator, SmallNetEvaluator
 
-            if engine.nn_dtype not in (torch.bfloat16, torch.float32):
-                raise EngineError("the fused evaluator exists in bf16 and f32: create the engine with one of these nn_dtypes")
-            # the engine's nn_dtype decides: f32 = the reference's own arithmetic (az_tower_f32.hip), bf16 = throughput mode
-            self.fused = FusedTowerEvaluator(model, "f32" if engine.nn_dtype == torch.float32 else "bf16")
-            if engine.game != GAME_GOMOKU or self.fused.board != engine.dims.height:
-                raise EngineError("the fused evaluator's board does not match the engine's game")
+            if engine.game == GAME_GOMOKU:
+                if engine.nn_dtype not in (torch.bfloat16, torch.float32):
+                    raise EngineError("the fused evaluator exists in bf16 and f32: create the engine with one of these nn_dtypes")
+                # the engine's nn_dtype decides: f32 = the reference's own arithmetic (az_tower_f32.hip), bf16 = throughput mode
+                self.fused = FusedTowerEvaluator(model, "f32" if engine.nn_dtype == torch.float32 else "bf16")
+                if self.fused.board != engine.dims.height:
+                    raise EngineError("the fused evaluator's board does not match the engine's game")
+            else:  # the reference's tic-tac-toe / dots-and-boxes networks: one f32 kernel per evaluation
+                self.fused = SmallNetEvaluator(model)
+                if self.fused.game != engine.game:
+                    raise EngineError("the fused evaluator's network does not match the engine's game")
             ring, leaf, _, _, flags = engine.leaf_buffers()
             self._packed = (ring, leaf, None, None, flags)  # flag mode: the tower skips terminal leaves by itself
 

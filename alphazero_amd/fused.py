@@ -225,3 +225,118 @@ class FusedTowerEvaluator:
         if rc != 0:
             raise EngineError(f"az_tower_heads_forward_static failed ({rc}): {self.lib.az_tower_last_error().decode()}")
         return logits, values
+
+
+class SmallNetEvaluator:
+    """The reference's two small example networks (examples/tictactoe/model.py, examples/dots_and_boxes/model.py;
+    alphazero_amd.nets.TicTacToeNet / DotsAndBoxesNet) as ONE float32 MFMA kernel per evaluation
+    (csrc/az_smallnet.hip: both convs, both heads, tanh; a workgroup per 7 / 4 boards, activations in LDS).  Same call
+    contract as FusedTowerEvaluator: ``(B, C_in, H, W) f32`` or the engine's packed leaf batch ->
+    ``(logits (B, A) f32, value (B, 1) f32)``; f32 operands and accumulation, the reference's precision."""
+
+    @staticmethod
+    def game_of(model: nn.Module):
+        """GAME_TICTACTOE / GAME_DAB when the module has exactly the layer sequence the kernel implements, else None"""
+        try:
+            sl, ph, vh = list(model._shared_layers), list(model._policy_head), list(model._value_head)
+            c1, c2 = sl[0], sl[2]
+            ok = len(sl) == 4 and isinstance(c1, nn.Conv2d) and isinstance(c2, nn.Conv2d) and isinstance(sl[1], nn.ReLU) and \
+                isinstance(sl[3], nn.ReLU) and c1.out_channels == 64 and (c2.in_channels, c2.out_channels) == (64, 64) and \
+                all(c.kernel_size == (3, 3) and c.padding == (1, 1) and c.bias is not None for c in (c1, c2))
+            if not ok:
+                return None
+            lin = lambda m, i, o: isinstance(m, nn.Linear) and (m.in_features, m.out_features) == (i, o) and m.bias is not None
+            if c1.in_channels == 9 and len(ph) == 4 and len(vh) == 5 and isinstance(ph[0], nn.Flatten) and lin(ph[1], 576, 128) and \
+                    isinstance(ph[2], nn.ReLU) and lin(ph[3], 128, 9) and isinstance(vh[0], nn.Flatten) and lin(vh[1], 576, 64) and \
+                    isinstance(vh[2], nn.ReLU) and lin(vh[3], 64, 1) and isinstance(vh[4], nn.Tanh):
+                return 0
+            conv1 = lambda m, o: isinstance(m, nn.Conv2d) and (m.in_channels, m.out_channels) == (64, o) and \
+                m.kernel_size == (1, 1) and m.bias is not None
+            if c1.in_channels == 25 and len(ph) == 4 and len(vh) == 7 and conv1(ph[0], 2) and isinstance(ph[1], nn.ReLU) and \
+                    isinstance(ph[2], nn.Flatten) and lin(ph[3], 32, 24) and conv1(vh[0], 1) and isinstance(vh[1], nn.ReLU) and \
+                    isinstance(vh[2], nn.Flatten) and lin(vh[3], 16, 64) and isinstance(vh[4], nn.ReLU) and lin(vh[5], 64, 1) and \
+                    isinstance(vh[6], nn.Tanh):
+                return 1
+        except Exception:
+            pass
+        return None
+
+    @classmethod
+    def supports(cls, model: nn.Module) -> bool:
+        return cls.game_of(model) is not None
+
+    def __init__(self, model: nn.Module):
+        self.game = self.game_of(model)
+        if self.game is None:
+            raise EngineError("SmallNetEvaluator: not the reference's tic-tac-toe or dots-and-boxes network")
+        self.lib = load_library()
+        self.model = model
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise EngineError("SmallNetEvaluator needs the model on a GPU")
+        self.cin, self.cinp, self.hw, self.n_action = ((9, 16, 3, 9), (25, 32, 4, 24))[self.game]
+        self.precision, self.in_dtype = "f32", torch.float32
+        self._buf = {}
+        self.kernel_events = None
+        self.refresh()
+
+    @staticmethod
+    def _pack3x3(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
+        """(64, ci, 3, 3) -> [tap 9][ci chunk][co 64][4 ci] f32"""
+        co, ci = w.shape[0], w.shape[1]
+        if ci < cin_pad:
+            w = torch.cat([w, w.new_zeros(co, cin_pad - ci, 3, 3)], 1)
+        return w.permute(2, 3, 1, 0).reshape(9, cin_pad // 4, 4, co).permute(0, 1, 3, 2).contiguous()
+
+    @torch.no_grad()
+    def refresh(self) -> None:
+        m, dev = self.model, self.device
+        f = lambda t: t.detach().float().cpu()
+        sl, ph, vh = list(m._shared_layers), list(m._policy_head), list(m._value_head)
+        self.w1 = self._pack3x3(f(sl[0].weight), self.cinp).to(dev)
+        self.b1 = f(sl[0].bias).to(dev).contiguous()
+        self.w2 = self._pack3x3(f(sl[2].weight), 64).to(dev)
+        self.b2 = f(sl[2].bias).to(dev).contiguous()
+        if self.game == 0:
+            w = torch.cat([f(ph[1].weight), f(vh[1].weight)])  # (192, 576), column c * 9 + pos (Flatten of (64, 3, 3))
+            w = w.view(192, 64, 9).permute(2, 1, 0).reshape(36, 4, 4, 192)  # [pos * 4 + m][kq][j][n]: channel 16 m + 4 kq + j
+            parts = [w.permute(0, 1, 3, 2), torch.cat([f(ph[1].bias), f(vh[1].bias)]), f(ph[3].weight), f(ph[3].bias),
+                     f(vh[3].weight), f(vh[3].bias)]
+        else:
+            parts = [torch.cat([f(ph[0].weight).view(2, 64), f(vh[0].weight).view(1, 64)]), torch.cat([f(ph[0].bias), f(vh[0].bias)]),
+                     f(ph[3].weight), f(ph[3].bias), f(vh[3].weight), f(vh[3].bias), f(vh[5].weight), f(vh[5].bias)]
+        head = torch.cat([p.contiguous().reshape(-1) for p in parts])
+        assert head.numel() == int(self.lib.az_smallnet_head_floats(self.game))
+        self.head = head.to(dev).contiguous()
+
+    def __call__(self, x: torch.Tensor | None, logits_out: torch.Tensor | None = None, packed=None, n_boards: int = 0):
+        if x is not None:
+            if x.dtype != torch.float32 or not x.is_contiguous() or x.device != self.device or \
+                    tuple(x.shape[1:]) != (self.cin, self.hw, self.hw):
+                raise EngineError(f"SmallNetEvaluator expects a contiguous (B,{self.cin},{self.hw},{self.hw}) float32 batch on the model's GPU")
+            B, ring_p, leaf_p, flags_p = x.shape[0], None, None, None
+        else:
+            if packed is None or n_boards < 1:
+                raise EngineError("SmallNetEvaluator: give either x or packed=(ring, leaf[, list, count, flags]) with n_boards")
+            B, ring_p, leaf_p = n_boards, C.c_void_p(packed[0]), C.c_void_p(packed[1])
+            flags_p = C.c_void_p(packed[4]) if len(packed) > 4 and packed[4] else None
+        if B not in self._buf:
+            self._buf[B] = (torch.empty(B, self.n_action, device=self.device), torch.empty(B, device=self.device))
+        logits_own, value = self._buf[B]
+        logits = logits_out if logits_out is not None else logits_own
+        if logits.dtype != torch.float32 or not logits.is_contiguous() or tuple(logits.shape) != (B, self.n_action):
+            raise EngineError("SmallNetEvaluator: logits_out must be a contiguous (B, n_action) float32 tensor")
+        P = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            if self.kernel_events is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            rc = self.lib.az_smallnet_forward_f32(self.game, B, P(x) if x is not None else None, ring_p, leaf_p, flags_p,
+                                                  P(self.w1), P(self.b1), P(self.w2), P(self.b2), P(self.head), P(logits), P(value), st)
+            if rc != 0:
+                raise EngineError(f"az_smallnet_forward_f32 failed ({rc}): {self.lib.az_tower_last_error().decode()}")
+            if self.kernel_events is not None:
+                ev1.record()
+                self.kernel_events.append((ev0, ev1))
+        return logits, value.view(B, 1)

@@ -151,11 +151,12 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     d = eng.dims
     evaluator = args.evaluator
     if evaluator == "auto":
-        from alphazero_amd.fused import FusedTowerEvaluator
+        from alphazero_amd.fused import FusedTowerEvaluator, SmallNetEvaluator
 
         kw_ = WORKLOADS[args.workload][4]
         f32_ok = kw_.get("channels") == 64 or (kw_.get("channels") == 128 and kw_.get("board_size") == 15)
         ok = FusedTowerEvaluator.supports(model) and (tdtype == torch.bfloat16 or (tdtype == torch.float32 and f32_ok))
+        ok = ok or (game != 2 and tdtype == torch.float32 and SmallNetEvaluator.supports(model))  # az_smallnet.hip (f32 only)
         evaluator = "fused" if ok else "model"
     run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))
     if evaluator == "hash":  # tree kernels alone (no network)
@@ -379,7 +380,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
                  + 32.0 * st["sum_depth"] + 36.0 * st["sims"]) / launches
     # the tree work of a simulation step is ONE launch: backup of simulation i + descent of simulation i+1
     dom = ("k_expand_select", sel_bytes + exp_bytes, tree_ms)
-    tower_kernel = "k_tower_f32" if dtype_name == "f32" else "k_tower"
+    tower_kernel = "k_smallnet_f32" if game != 2 else ("k_tower_f32" if dtype_name == "f32" else "k_tower")
 
     # HBM traffic from PMC counters cannot be collected inside this run (separate rocprofv3 --pmc passes,
     # scripts/pmc_traffic.sh); the last committed measurement of this same workload is reported, if present
@@ -403,28 +404,37 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     evals_per_launch = st["evals"] / launches  # boards the network really evaluates per simulation step
     roofline = tree_roofline
     nn_eval = None
-    if evaluator in ("model", "fused") and hasattr(model, "flops_per_eval"):
+    if evaluator in ("model", "fused"):
         import torch.nn as tnn
         conv_flops = sum(2.0 * d.height * d.width * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
                          for m in model.modules() if isinstance(m, tnn.Conv2d))
-        fl = model.flops_per_eval() * evals_per_launch
+        lin_flops = sum(2.0 * m.in_features * m.out_features for m in model.modules() if isinstance(m, tnn.Linear))
+        flops_per_eval = model.flops_per_eval() if hasattr(model, "flops_per_eval") else conv_flops + lin_flops
+        fl = flops_per_eval * evals_per_launch
         nn_eval = {"bound": "mfma", "ms_per_batch": nn_ms, "achieved": fl / (nn_ms * 1e-3) / 1e12 if nn_ms else 0.0,
                    "peak": peak, "unit": "TFLOP/s", "frac": (fl / (nn_ms * 1e-3) / 1e12 / peak) if nn_ms else 0.0,
-                   "flops_per_eval": model.flops_per_eval(), "boards_per_batch": evals_per_launch,
+                   "flops_per_eval": flops_per_eval, "boards_per_batch": evals_per_launch,
                    "share_of_step": nn_ms / max(nn_ms + tree_ms, 1e-9),
-                   "implementation": (("az_tower_f32.hip: k_tower_f32 (f32 MFMA conv tower) + k_heads_f32" if dtype_name == "f32" else
+                   "implementation": (("az_smallnet.hip: k_smallnet_f32 (the whole network, one f32 MFMA kernel)" if game != 2 else
+                                       "az_tower_f32.hip: k_tower_f32 (f32 MFMA conv tower) + k_heads_f32" if dtype_name == "f32" else
                                        "az_tower.hip: k_tower (fused bf16 MFMA conv tower) + k_heads (MFMA head linears)")
                                       if evaluator == "fused" else "PyTorch/MIOpen module forward")}
         if evaluator == "fused" and tower_ms_raw is not None:
             # the dominant kernel of the step: the fused conv tower (MFMA bound).  Algorithmic flops = the convolutions'
             # multiply-adds x 2 for the boards this launch evaluates (terminal leaves are skipped, padding is not counted)
             tw_ms = corr(tower_ms_raw)
-            tw_fl = conv_flops * evals_per_launch
+            tw_fl = (conv_flops if game == 2 else flops_per_eval) * evals_per_launch  # k_smallnet_f32 holds the head layers too
             ttraffic, tnote = pmc_traffic(tower_kernel)
-            roofline = {"bound": "mfma", "kernel": tower_kernel, "achieved": tw_fl / (tw_ms * 1e-3) / 1e12, "peak": peak,
+            net_roofline = {"bound": "mfma", "kernel": tower_kernel, "achieved": tw_fl / (tw_ms * 1e-3) / 1e12, "peak": peak,
                         "unit": "TFLOP/s", "frac": tw_fl / (tw_ms * 1e-3) / 1e12 / peak, "traffic": ttraffic,
                         "traffic_note": tnote, "flops_per_launch": tw_fl, "boards_per_launch": evals_per_launch,
                         "ms_per_launch": tw_ms, "share_of_step": tw_ms / max(nn_ms + tree_ms, 1e-9)}
+            # the dominant kernel of the step: the network kernel for the gomoku towers; for the two small nets the tree
+            # kernel runs longer than the whole network and stays the headline roofline
+            if game == 2 or tw_ms >= tree_ms:
+                roofline = net_roofline
+            else:
+                nn_eval["roofline_network_kernel"] = net_roofline
     out = {
         "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,

@@ -274,6 +274,25 @@ int az_heads_forward_f32(int32_t board_size, int32_t n_boards, const float *feat
                          const float *bp_dev, const void *w1_dev, const float *b1_dev, const float *w2_dev, float b2,
                          float *logits_dev, float *values_dev, void *stream);
 
+/* The reference's two small example networks, one launch per evaluation, float32 on v_mfma_f32_16x16x4_f32 (the
+ * reference's precision): examples/tictactoe/model.py (game AZ_GAME_TICTACTOE, input (B,9,3,3), 9 logits) and
+ * examples/dots_and_boxes/model.py (game AZ_GAME_DAB, input (B,25,4,4), 24 logits); contract nn_models/base.py:17-19
+ * ((policy logits, value in [-1,1])).  Input: x_f32_dev dense planes, or NULL = the engine's packed leaf batch
+ * (packed_ring_dev / packed_leaf_dev from az_get_buffers, flags_dev = the needs-the-network bytes or NULL = all);
+ * slots whose flag is 0 keep their logits / values rows.  Weights (device, packed by the host mirror
+ * alphazero_amd/fused.py:SmallNetEvaluator): w1_dev [9 taps][C_in_padded/4][64][4] f32 (C_in padded to 16 / 32 with zeros),
+ * w2_dev [9][16][64][4] f32, b1_dev / b2_dev [64]; head_dev = az_smallnet_head_floats(game) floats:
+ *   tic-tac-toe:    W1' [36][4][192][4] (rows 0..127 the policy head's hidden layer, 128..191 the value head's; k = cell * 64 +
+ *                   channel), b1' [192], policy Linear(128->9) weight [9][128] and bias [9], value Linear(64->1) weight [64], bias [1];
+ *   dots-and-boxes: 1x1 head convs [3][64] (2 policy rows, 1 value row) and biases [3], policy Linear(32->24) [24][32] + [24],
+ *                   value Linear(16->64) [64][16] + [64], Linear(64->1) [64] + [1].
+ * Errors through az_tower_last_error(). */
+int32_t az_smallnet_head_floats(int32_t game);
+int az_smallnet_forward_f32(int32_t game, int32_t n_boards, const float *x_f32_dev, const void *packed_ring_dev,
+                            const void *packed_leaf_dev, const void *flags_dev, const void *w1_dev, const float *b1_dev,
+                            const void *w2_dev, const float *b2_dev, const float *head_dev, float *logits_dev, float *values_dev,
+                            void *stream);
+
 /* No counterpart in the reference.  For callers that CANNOT allocate device memory around the evaluation -- code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: az_tower_forward followed by
  * az_heads_forward in one call, with the feature rows that travel between the two kernels kept in a static array
