@@ -41,7 +41,12 @@ def test_bench_line_gomoku_f32_primary_with_bf16_beside_it_under_rccl():
     assert 0.5 <= a["same_most_visited_move"] <= 1.0 and a["positions"] > 0
 
 
-def test_bench_line_small_game_through_pytorch():
-    d = _run(["--workload", "dab", "--slots", "128", "--sims", "16", "--graph", "1", "--no-cpu-baseline"])
+def test_bench_line_small_game_fused_and_through_pytorch():
+    base = ["--workload", "dab", "--slots", "128", "--sims", "16", "--graph", "1", "--no-cpu-baseline"]
+    d = _run(base)  # auto: the one-kernel f32 network of az_smallnet.hip
     assert d["dtype"] == "f32" and d["value"] > 0 and d["cpu_baseline"] is None and "throughput_mode" not in d
-    assert d["roofline"]["kernel"] == "k_expand_select"  # no fused evaluator for this net: the tree kernel's HBM roofline
+    assert "evaluator=fused" in d["config"]["workload"] and "k_smallnet_f32" in d["nn_eval"]["implementation"]
+    kernels = {d["roofline"]["kernel"], d["nn_eval"].get("roofline_network_kernel", {}).get("kernel")}
+    assert "k_smallnet_f32" in kernels and d["roofline_tree"]["kernel"] == "k_expand_select"
+    d = _run(base + ["--evaluator", "model"])  # the module's own PyTorch forward: the tree kernel's HBM roofline leads
+    assert d["roofline"]["kernel"] == "k_expand_select" and "PyTorch" in d["nn_eval"]["implementation"]
