@@ -411,33 +411,39 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
   const int woff = kq * (CW * 16) + (ch * 32 + r) * 16, loff = kq * (CW * 16) + (wave * 16 + r) * 16;
   const char *wlane = wg + woff, *llane = wg + loff;
-  uint32_t bb[7], lx32 = 0;
-  auto tap_bb = [&](int tap, int pt) -> uint32_t {  // (the lane's cells are pp0 + 16 pt; bit 9 pt + tap of vm: that tap is on the board)
+  // Fragment addresses of the running tap, LDS base included (the activation buffer starts the 1024-byte aligned dynamic
+  // LDS, so XOR-ing the k-step's chunk bits into the finished address is the same as into the offset).  Per tap: one base for
+  // the lane's first cell (its swizzle nibble is the same for all seven cells: they are 16 apart) and the tap's seven
+  // on-the-board bits; per cell tile an add and a select -- these VALU instructions do not overlap with the f32 MFMAs.
+  uint32_t bb[7], lx32 = 0, tbase = 0, tmask = 0;
+  const uint32_t zaddr = act32 + (uint32_t)(ZERO_OFF | (kq << 4));
+  auto tap_head = [&](int tap) {  // (bit 7 tap + pt of vm: that tap of cell pp0 + 16 pt is on the board)
     const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
-    const uint32_t q = (uint32_t)(pp0 + 16 * pt + d);
-    const uint32_t in = (q * ROWW) | (((q & 15u) ^ (uint32_t)kq) << 4);
-    return ((vm >> (9 * pt + tap)) & 1ull) ? in : (uint32_t)(ZERO_OFF | (kq << 4));
+    const uint32_t q0 = (uint32_t)(pp0 + d);  // may be "negative": only added to 16 pt ROWW below, and masked when off the board
+    tbase = act32 + ((q0 * ROWW) | (((q0 & 15u) ^ (uint32_t)kq) << 4));
+    tmask = (uint32_t)(vm >> (7 * tap));
   };
   auto set_tap_A = [&](int tap) {
+    tap_head(tap);
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) bb[pt] = tap_bb(tap, pt);
+    for (int pt = 0; pt < 4; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWW) : zaddr;
     // cell 224: taps with dr <= 0 and dc <= 0 are on the board for that corner cell; the others read the zero row
     const uint32_t lq = (uint32_t)(LCELL + (tap / 3 - 1) * N + (tap % 3 - 1));
-    lx32 = act32 + ((tap / 3 <= 1 && tap % 3 <= 1) ? ((lq * ROWW) | (((lq & 15u) ^ (uint32_t)kq) << 4)) : (uint32_t)(ZERO_OFF | (kq << 4)));
+    lx32 = (tap / 3 <= 1 && tap % 3 <= 1) ? act32 + ((lq * ROWW) | (((lq & 15u) ^ (uint32_t)kq) << 4)) : zaddr;
   };
-  auto set_tap_B = [&](int tap) {
+  auto set_tap_B = [&](int) {  // (after set_tap_A of the same tap)
 #pragma unroll
-    for (int pt = 4; pt < 7; ++pt) bb[pt] = tap_bb(tap, pt);
+    for (int pt = 4; pt < 7; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWW) : zaddr;
   };
   f32x4 fbA[4], fbB[3], lx;
   auto loadA = [&](int m) {  // 5 LDS reads: cell tiles 0..3 and the operand of cell 224
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) asm volatile("ds_read_b128 %0, %1" : "=v"(fbA[pt]) : "v"(act32 + (bb[pt] ^ (uint32_t)(m << 6))));
+    for (int pt = 0; pt < 4; ++pt) asm volatile("ds_read_b128 %0, %1" : "=v"(fbA[pt]) : "v"(bb[pt] ^ (uint32_t)(m << 6)));
     asm volatile("ds_read_b128 %0, %1" : "=v"(lx) : "v"(lx32 ^ (uint32_t)(m << 6)));
   };
   auto loadB = [&](int m) {  // 3 LDS reads: cell tiles 4..6
 #pragma unroll
-    for (int pt = 0; pt < 3; ++pt) asm volatile("ds_read_b128 %0, %1" : "=v"(fbB[pt]) : "v"(act32 + (bb[4 + pt] ^ (uint32_t)(m << 6))));
+    for (int pt = 0; pt < 3; ++pt) asm volatile("ds_read_b128 %0, %1" : "=v"(fbB[pt]) : "v"(bb[4 + pt] ^ (uint32_t)(m << 6)));
   };
   set_tap_A(0);
   set_tap_B(0);
@@ -499,9 +505,9 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
   constexpr int C = CW, ROW = 4 * CW, NW = CW / 16, NTH = 64 * NW, NCQ = CW / 32;  // waves; channel groups of 32
   constexpr int ACT_BYTES = NV * ROW + ROW, HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16, RG_BYTES = ((RGW + 4) * 4 + 15) / 16 * 16;
   constexpr int KSB16 = 4 * C * 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *act = smem;
-  float *hw = (float *)(smem + ACT_BYTES);
+  extern __shared__ __attribute__((aligned(1024))) char smem_t16[];  // (conv_layer16g XORs chunk bits into finished addresses)
+  char *act = smem_t16;
+  float *hw = (float *)(smem_t16 + ACT_BYTES);
   uint32_t *rg = (uint32_t *)((char *)hw + HW_BYTES);  // RGW ring words, player, slot, ticket
   int *slots = (int *)rg + RGW + 1;   // {this board's slot, its ticket (G = past the end), the slot looked up ahead}
   float *hp = (float *)((char *)rg + RG_BYTES);         // [NCQ channel groups][3 heads][225 cells]: partial head sums
@@ -516,14 +522,14 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
   for (int i = tid; i < (1 + L) * C; i += NTH) bl[i] = bias[i];
 
   const int pp0 = 7 * chalf * 16 + (lane & 15);  // this lane's cells: pp0 + 16 pt
-  unsigned long long vm = 0;                      // bit 9 pt + tap: tap of that cell is on the board
+  unsigned long long vm = 0;                      // bit 7 tap + pt: that tap of cell pp0 + 16 pt is on the board
 #pragma unroll
   for (int pt = 0; pt < 7; ++pt) {
     const int cell = pp0 + 16 * pt, row = cell / N, col = cell % N;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int rr = row + t / 3 - 1, cc = col + t % 3 - 1;
-      if (rr >= 0 && rr < N && cc >= 0 && cc < N) vm |= 1ull << (9 * pt + t);
+      if (rr >= 0 && rr < N && cc >= 0 && cc < N) vm |= 1ull << (7 * t + pt);
     }
   }
   WFrag wf[2];  // weight fragments of the running and the next k-step (global -> registers, one k-step ahead)
