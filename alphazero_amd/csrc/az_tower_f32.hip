@@ -393,12 +393,14 @@ constexpr int T16_MAX_LAYERS = 40;  // bias rows the 16-cell-tile kernel keeps i
 // launch (the partner wave of the SIMD does not reliably cover them).
 struct WFrag { f32x4 a0, a1, l; };  // a lane's weights of one k-step: both channel tiles + its row for cell 224
 
+// (uniform base + 32-bit lane offset: the loads take the scalar-base addressing mode, no 64-bit VALU address arithmetic)
 template <int CW>
-__device__ __forceinline__ void wload(WFrag &w, const char *wlane, const char *llane, int kk) {
+__device__ __forceinline__ void wload(WFrag &w, const char *wg, uint32_t woff, uint32_t loff, int kk) {
   constexpr int KSBW = 4 * CW * 16;  // bytes of one k-step of 16 input channels: [kq 4][co CW][4] f32
-  w.a0 = *(const f32x4 *)(wlane + (size_t)kk * KSBW);
-  w.a1 = *(const f32x4 *)(wlane + (size_t)kk * KSBW + 256);
-  w.l = *(const f32x4 *)(llane + (size_t)kk * KSBW);
+  const char *base = wg + (size_t)kk * KSBW;
+  w.a0 = *(const f32x4 *)(base + woff);
+  w.a1 = *(const f32x4 *)(base + woff + 256);
+  w.l = *(const f32x4 *)(base + loff);
 }
 
 // On entry wf[0] holds (or is about to receive) k-step 0 of this layer; the weights of wnext's k-step 0 are requested
@@ -409,8 +411,7 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
   constexpr int N = 15, ROWW = 4 * CW, ZERO_OFF = 225 * ROWW, LCELL = 224;
   const int kq = lane >> 4, r = lane & 15, ch = wave >> 1;
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
-  const int woff = kq * (CW * 16) + (ch * 32 + r) * 16, loff = kq * (CW * 16) + (wave * 16 + r) * 16;
-  const char *wlane = wg + woff, *llane = wg + loff;
+  const uint32_t woff = kq * (CW * 16) + (ch * 32 + r) * 16, loff = kq * (CW * 16) + (wave * 16 + r) * 16;
   // Fragment addresses of the running tap, LDS base included (the activation buffer starts the 1024-byte aligned dynamic
   // LDS, so XOR-ing the k-step's chunk bits into the finished address is the same as into the offset).  Per tap: one base for
   // the lane's first cell (its swizzle nibble is the same for all seven cells: they are 16 apart) and the tap's seven
@@ -456,8 +457,8 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
       if (k >= KSTEPS) break;
       const bool last = k + 1 >= KSTEPS;
       // the next k-step's weights (the next layer's first, at the end): in flight under this k-step's 56 MFMAs
-      if (!last) wload<CW>(wf[(u + 1) & 1], wlane, llane, k + 1);
-      else if (wnext != nullptr) wload<CW>(wf[(u + 1) & 1], wnext + woff, wnext + loff, 0);
+      if (!last) wload<CW>(wf[(u + 1) & 1], wg, woff, loff, k + 1);
+      else if (wnext != nullptr) wload<CW>(wf[(u + 1) & 1], wnext, woff, loff, 0);
       loadB(k % KS16);
       asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");  // group A of this k-step has returned
       __builtin_amdgcn_sched_barrier(0);
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     }
   }
   WFrag wf[2];  // weight fragments of the running and the next k-step (global -> registers, one k-step ahead)
-  wload<CW>(wf[0], w0 + kq * (C * 16) + (ch * 32 + (lane & 15)) * 16, w0 + kq * (C * 16) + (wave * 16 + (lane & 15)) * 16, 0);  // the stem's first
+  wload<CW>(wf[0], w0, (uint32_t)(kq * (C * 16) + (ch * 32 + (lane & 15)) * 16), (uint32_t)(kq * (C * 16) + (wave * 16 + (lane & 15)) * 16), 0);  // the stem's first
   // Boards are handed out by the ticket counter.  The NEXT board is looked up while the current one is computed, in steps
   // that are never waited for: the returning atomic is issued at the top of the board; after the stem thread 0 reads the
   // ticket's flag byte; before the first block's barrier it publishes the slot (or -2: flagged off, look again at the
