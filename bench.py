@@ -229,14 +229,18 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     ev_tree, ev_nn, ev_tower = [], [], []
     EVENT_EVERY = 8  # every 8th simulation step of the timed region is bracketed with HIP events
 
+    phase = [0]
+
     def timed_round():
         """run.move_round with HIP events around each tree kernel and each network forward"""
+        ph = phase[0] % EVENT_EVERY  # which simulations are bracketed rotates from move to move: an unbiased sample of the
+        phase[0] += 3                # move (its first launches share the chip with the previous move's sample copy)
         noise = run.draw_noise()
         nn_in = None if run.fused is not None else run.nn_input
         eng.begin_search()
         eng.select_gather(nn_in)  # the move's first descent; every later one rides with the previous simulation's backup
         for k in range(sims - 1):
-            if k % EVENT_EVERY:  # un-bracketed simulation step (an event record costs the stream ~5 us)
+            if (k + ph) % EVENT_EVERY:  # un-bracketed simulation step (an event record costs the stream ~5 us)
                 if run.fused is not None:
                     run.fused.kernel_events = None
                 run.eval_step(noise)
@@ -566,6 +570,18 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the "
                     "barrier / all-reduce / weight-broadcast path on a one-GPU box")
     args = ap.parse_args()
+
+    # a line on stderr every 45 s: the deep configurations run minutes between two outputs, and a harness that watches for
+    # silence would take them for hung
+    import threading
+    t_start = time.perf_counter()
+
+    def _heartbeat():
+        while True:
+            time.sleep(45.0)
+            print(f"[bench] running, {time.perf_counter() - t_start:.0f} s", file=sys.stderr, flush=True)
+
+    threading.Thread(target=_heartbeat, daemon=True).start()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
