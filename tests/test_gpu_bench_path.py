@@ -155,3 +155,42 @@ def test_runner_search_graph_replay_matches_eager(oracle):
         out.append(_results(eng))
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_full_size_bench_path_properties(oracle, precision):
+    """BASELINE configs[3] at its full size -- 16,384 gomoku-15 trees through SelfPlayRunner.search() with the fused tower on
+    the packed + flags path -- checked through size-independent properties: two distinct root positions alternate over the
+    slots, so (no noise, deterministic tower) every even slot must grow the same tree and every odd slot the same tree,
+    whichever workgroup, ticket or launch evaluated its leaves; both trees equal the oracle's with the same tower as its
+    evaluator; visit sums, pi normalisation and the engine's counters hold for all slots."""
+    from alphazero_amd import Engine
+    from alphazero_amd.arena import SelfPlayRunner
+    from alphazero_amd.nets import GomokuNet
+
+    n, G, sims = 15, 16384, 20
+    rng = np.random.default_rng(77)
+    torch.manual_seed(5)
+    dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+    net = _randomised(GomokuNet(n, 64, 2)).eval().cuda().to(dtype)
+    eng = Engine(2, G, sims, board_size=n, nn_dtype=dtype, device="cuda:0")
+    A = eng.dims.n_action
+    pos = [_random_position(oracle, 2, n, m, rng) for m in (9, 30)]
+    for g in range(G):
+        eng.set_position(g, *pos[g & 1])
+    run = SelfPlayRunner(eng, net, sims, fused=True, use_dirichlet=False)
+    run.search()
+    pi, visits, q, prior = _results(eng)
+    assert (visits.sum(1) == sims - 1).all()
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-5)
+    for par in (0, 1):
+        assert (visits[par::2] == visits[par]).all(), par
+        assert (q[par::2] == q[par]).all() and (prior[par::2] == prior[par]).all(), par
+    st = eng.read_stats()
+    assert st["sims"] == G * sims and st["evals"] + st["terminals"] == st["sims"]
+    d = oracle.dims(2, n)
+    cb, _calls = _tower_callback(run.fused, (d["cin"], d["H"], d["W"]), dtype)
+    for par, (h, p) in enumerate(pos):
+        r = oracle.search(2, n, h[-1], p, h, sims, cb)
+        assert np.array_equal(visits[par], r["visits"]) and np.array_equal(q[par], r["child_q"])
+        assert np.array_equal(prior[par], r["root_prior"]) and np.array_equal(pi[par], r["pi"])
