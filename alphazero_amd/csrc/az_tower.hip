@@ -185,18 +185,21 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
   const int h = lane >> 5, r = lane & 31, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cot0 = C > 64 ? (wave >> 2) * 2 : 0;  // this wave's first 32-channel output tile
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
+  // Finished LDS addresses (base included: the activation buffer starts the 1024-byte aligned dynamic LDS, so the k-step's
+  // chunk bits can be XOR-ed into them).  A lane's NPT cells are 32 apart, so they share the swizzle term of a tap: one base
+  // per tap, then an add and a select per cell tile (a lane whose tile is padding has vm == 0 and reads the zero row).
   uint32_t bb[ST][NPT];
+  const uint32_t zaddr = act32 + (uint32_t)(ZERO_OFF | (h << 4));
   auto bases = [&](int sg) {
 #pragma unroll
     for (int j = 0; j < ST; ++j) {
       const int tap = sg * ST + j;
       const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
+      const uint32_t q0 = (uint32_t)(pp[0] + d);  // ("negative" for the first cells: only used with 32 pt rows added, or masked)
+      const uint32_t base = act32 + (C == 64 ? (q0 << 7) | ((((q0 >> 1) & 7u) ^ (uint32_t)h) << 4) : (q0 << 8) | (((q0 & 15u) ^ (uint32_t)h) << 4));
 #pragma unroll
-      for (int pt = 0; pt < NPT; ++pt) {
-        const uint32_t q = (uint32_t)(pp[pt] + d);
-        const uint32_t in = C == 64 ? (q << 7) | ((((q >> 1) & 7u) ^ (uint32_t)h) << 4) : (q << 8) | (((q & 15u) ^ (uint32_t)h) << 4);
-        bb[j][pt] = ((vm[pt] >> tap) & 1u) ? in : (uint32_t)(ZERO_OFF | (h << 4));
-      }
+      for (int pt = 0; pt < NPT; ++pt)
+        bb[j][pt] = ((vm[pt] >> tap) & 1u) ? base + (uint32_t)(pt * 32 * (C == 64 ? 128 : 256)) : zaddr;
     }
   };
   bf16x8 fa[2][2], fb[2][NPT];
@@ -208,7 +211,7 @@ __device__ __forceinline__ void conv_layer(const char *act, char *wbuf, int &buf
 #endif
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt)
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][pt]) : "v"(act32 + (bb[j][pt] ^ (uint32_t)(ks << 5))));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][pt]) : "v"(bb[j][pt] ^ (uint32_t)(ks << 5)));
   };
   bases(0);
   if (XPF) load_b(0, 0);
@@ -459,7 +462,8 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) voi
 #else
   constexpr int ST0 = 9 * 2 * Q::KB <= STAGE_BYTES ? 9 : (3 * 2 * Q::KB <= STAGE_BYTES ? 3 : 1);
 #endif
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(1024))) char smem_bf16[];  // (conv_layer XORs chunk bits into finished addresses)
+  char *const smem = smem_bf16;
   char *act = smem;
   char *wbuf = smem + Q::ACT_BYTES;
   float *hw = (float *)(wbuf + 2 * STAGE_BYTES);  // 3*C + 3 floats
