@@ -28,6 +28,7 @@
 #include "../../include/az_engine.h"
 
 void tower_set_error(const std::string &msg);  // az_tower.hip (az_tower_last_error)
+int tower_device(hipStream_t stream, int *dev);  // az_tower.hip: the device that owns the stream (current device for the NULL stream)
 
 namespace azsmall {
 
@@ -277,6 +278,14 @@ int az_smallnet_forward_f32(int32_t game, int32_t n_boards, const float *x_f32_d
       !values_dev) { tower_set_error("null argument"); return AZ_EINVAL; }
   if (n_boards < 1 || (game != AZ_GAME_TICTACTOE && game != AZ_GAME_DAB)) { tower_set_error("n_boards >= 1; game tic-tac-toe or dots-and-boxes"); return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
+  int dev = 0, cur = 0;
+  if (tower_device(s, &dev) != 0) { tower_set_error("cannot tell the stream's device"); return AZ_EHIP; }
+  if (hipGetDevice(&cur) != hipSuccess) { tower_set_error("hipGetDevice failed"); return AZ_EHIP; }
+  struct DeviceGuard {  // launch on the device that owns the stream, whatever the caller's current device is
+    int back;
+    DeviceGuard(int want, int cur_) : back(want != cur_ ? cur_ : -1) { if (back >= 0) (void)hipSetDevice(want); }
+    ~DeviceGuard() { if (back >= 0) (void)hipSetDevice(back); }
+  } guard(dev, cur);
   const uint8_t *fl = x_f32_dev ? nullptr : (const uint8_t *)flags_dev;
   if (game == AZ_GAME_TICTACTOE) {
     const int tb = Net<AZ_GAME_TICTACTOE>::TB;
