@@ -1,7 +1,9 @@
 """Virtual loss / in-tree leaf batching (az_select_wave / az_expand_wave) against the oracle's restatement of the same
 rule (oracle/az_oracle.c: az_oracle_search_wave; the reference carries the hooks -- core/MCTS_alphazero.py:32-33,70,
 config/basic.py:19-30 -- but no code that uses them, so the rule is this repository's and is stated in both places).
-K = 1 must be the sequential search bit for bit; K > 1 must match the oracle bit for bit (visits, Q, priors, pi)."""
+K = 1 must be the sequential search bit for bit; K > 1 must match the oracle bit for bit (visits, Q, priors, pi).
+PARITY UNPINNED for K > 1: no reference code, fixture or golden vector exists for this mode -- the comparison is engine vs
+this repository's own CPU statement of the rule, not vs the reference; K = 1 is pinned through the sequential search."""
 import numpy as np
 import pytest
 import torch
