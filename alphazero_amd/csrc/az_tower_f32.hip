@@ -27,6 +27,8 @@
 
 #include <mutex>
 #include <string>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/az_engine.h"
 
@@ -391,107 +393,156 @@ constexpr int T16_MAX_LAYERS = 40;  // bias rows the 16-cell-tile kernel keeps i
 // ahead through two register groups that are re-used as soon as their MFMAs have been issued: group A = cell tiles 0..3 +
 // the operand of cell 224, group B = cell tiles 4..6; with every k-step's reads exposed the MFMA pipe idled 20 % of the
 // launch (the partner wave of the SIMD does not reliably cover them).
-struct WFrag { f32x4 a0, a1, l; };  // a lane's weights of one k-step: both channel tiles + its row for cell 224
+// A lane's weights of one k-step, for both 16-channel tiles of its wave's 32 channels.  ODD waves hold the tiles SWAPPED: a0 =
+// channels 32 ch + 16 .. + 31, a1 = 32 ch .. + 15 (accumulator tile ct of wave w is channel tile 2 ch + (ct ^ (w & 1))
+// everywhere in the kernel), so that a0's row is always channel 16 w + r -- the row cell 224's VALU sum needs: no third load.
+struct WFrag { f32x4 a0, a1; };
 
-// (uniform base + 32-bit lane offset: the loads take the scalar-base addressing mode, no 64-bit VALU address arithmetic)
+// Weight requests: uniform base + the lane's 32-bit offset, ordinary loads whose waits the compiler counts.  (Tried: the same
+// requests as inline asm in the scalar-base form with hand-counted `s_waitcnt vmcnt(6)` -- 51 instead of 59 VALU instructions
+// per tap and no conservative wait at the loop header, but the register allocator copies three of the four a0 fragments at
+// the end of every tap (loop-carried values), and a copy of a register whose load is still in flight reads stale data: the
+// compiler must know about these loads.)
 template <int CW>
-__device__ __forceinline__ void wload(WFrag &w, const char *wg, uint32_t woff, uint32_t loff, int kk) {
+__device__ __forceinline__ void wload(WFrag &w, const char *wg, uint32_t woff, int cto, int kk) {
   constexpr int KSBW = 4 * CW * 16;  // bytes of one k-step of 16 input channels: [kq 4][co CW][4] f32
+#ifdef AZ_F32_WSAME  // diagnostic build: every k-step reads k-step 0's weights (always cache hits; wrong results, timing only)
+  kk = 0;
+#endif
+  // woff = the lane's offset in the wave pair's FIRST tile; which tile a0 / a1 take is uniform per wave (cto) and goes into
+  // the scalar base: one 32-bit lane offset serves both loads
   const char *base = wg + (size_t)kk * KSBW;
-  w.a0 = *(const f32x4 *)(base + woff);
-  w.a1 = *(const f32x4 *)(base + woff + 256);
-  w.l = *(const f32x4 *)(base + loff);
+  w.a0 = *(const f32x4 *)(base + cto * 256 + woff);
+  w.a1 = *(const f32x4 *)(base + (256 - cto * 256) + woff);
 }
 
-// On entry wf[0] holds (or is about to receive) k-step 0 of this layer; the weights of wnext's k-step 0 are requested
-// during the last k-step, into wf[KSTEPS & 1].  KS16 = k-steps per tap.  No barrier inside: the caller synchronises.
-template <int KSTEPS, int KS16, bool LEFT, int CW>
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int CNT, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, CNT>{}); }
+template <int OFF>
+__device__ __forceinline__ void dsr128(f32x4 &d, uint32_t a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "i"(OFF)); }
+
+// On entry wf[0..2] hold (or are about to receive) k-steps 0..2 of this layer; the weights of wnext's first k-steps are
+// requested during its last three (see step below).  KS16 = k-steps per tap.  No barrier inside: the caller synchronises.
+// The activation rows are PADDED, not swizzled (T16_ROW<CW> = 4 CW + 16 bytes per cell): a fragment address is then linear in
+// cell, k-step and k-quarter, so the k-step is the instruction's immediate offset and a tap costs one base, an add and a
+// select per cell tile -- no per-read VALU instruction at all (VALU does not overlap with f32 MFMAs: every one of them
+// is launch time).  The price is one 2-way bank conflict per 16-lane group of a ds_read_b128 (cells c .. c+15 of k-quarter
+// pairs land on 16-byte bank units (cell + kq + 4m) mod 16: the two quarters of a group overlap in one unit), on an LDS
+// array that is otherwise 11 % busy.  The loop runs over taps; the k-steps of a tap are unrolled.
+template <int CW> constexpr int T16_ROW = 4 * CW + 16;
+
+template <int KS16, bool LEFT, int CW>
 __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, const char *wnext, int wave, int lane, const int pp0,
-                                              const unsigned long long vm, f32x4 (&acc)[7][2], float &lc, WFrag (&wf)[2]) {
-  constexpr int N = 15, ROWW = 4 * CW, ZERO_OFF = 225 * ROWW, LCELL = 224;
+                                              const unsigned long long vm, f32x4 (&acc)[7][2], float &lc, WFrag (&wf)[4]) {
+  constexpr int N = 15, ROWP = T16_ROW<CW>, LCELL = 224;
   const int kq = lane >> 4, r = lane & 15, ch = wave >> 1;
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
-  const uint32_t woff = kq * (CW * 16) + (ch * 32 + r) * 16, loff = kq * (CW * 16) + (wave * 16 + r) * 16;
-  // Fragment addresses of the running tap, LDS base included (the activation buffer starts the 1024-byte aligned dynamic
-  // LDS, so XOR-ing the k-step's chunk bits into the finished address is the same as into the offset).  Per tap: one base for
-  // the lane's first cell (its swizzle nibble is the same for all seven cells: they are 16 apart) and the tap's seven
-  // on-the-board bits; per cell tile an add and a select -- these VALU instructions do not overlap with the f32 MFMAs.
+  const uint32_t woff = kq * (CW * 16) + (ch * 32 + r) * 16;  // row 32 ch + r; a0's row is channel 16 wave + r (tile cto of the pair), a1's the other tile
+  const int cto = wave & 1;
   uint32_t bb[7], lx32 = 0, tbase = 0, tmask = 0;
-  const uint32_t zaddr = act32 + (uint32_t)(ZERO_OFF | (kq << 4));
-  auto tap_head = [&](int tap) {  // (bit 7 tap + pt of vm: that tap of cell pp0 + 16 pt is on the board)
+  const uint32_t zaddr = act32 + (uint32_t)(225 * ROWP + (kq << 4));  // the zero row
+  auto set_tap_A = [&](int tap) {  // (bit 7 tap + pt of vm: that tap of cell pp0 + 16 pt is on the board)
     const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
-    const uint32_t q0 = (uint32_t)(pp0 + d);  // may be "negative": only added to 16 pt ROWW below, and masked when off the board
-    tbase = act32 + ((q0 * ROWW) | (((q0 & 15u) ^ (uint32_t)kq) << 4));
+    tbase = act32 + (uint32_t)((pp0 + d) * ROWP + (kq << 4));  // ("negative" rows only occur masked, or with 16 pt rows added)
     tmask = (uint32_t)(vm >> (7 * tap));
-  };
-  auto set_tap_A = [&](int tap) {
-    tap_head(tap);
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWW) : zaddr;
+    for (int pt = 0; pt < 4; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWP) : zaddr;
     // cell 224: taps with dr <= 0 and dc <= 0 are on the board for that corner cell; the others read the zero row
-    const uint32_t lq = (uint32_t)(LCELL + (tap / 3 - 1) * N + (tap % 3 - 1));
-    lx32 = (tap / 3 <= 1 && tap % 3 <= 1) ? act32 + ((lq * ROWW) | (((lq & 15u) ^ (uint32_t)kq) << 4)) : zaddr;
+    lx32 = (tap / 3 <= 1 && tap % 3 <= 1) ? act32 + (uint32_t)((LCELL + d) * ROWP + (kq << 4)) : zaddr;
   };
-  auto set_tap_B = [&](int) {  // (after set_tap_A of the same tap)
+  auto set_tap_B = [&]() {  // (after set_tap_A of the same tap)
 #pragma unroll
-    for (int pt = 4; pt < 7; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWW) : zaddr;
+    for (int pt = 4; pt < 7; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWP) : zaddr;
   };
   f32x4 fbA[4], fbB[3], lx;
-  auto loadA = [&](int m) {  // 5 LDS reads: cell tiles 0..3 and the operand of cell 224
+  auto loadA = [&](auto mc) {  // 5 LDS reads: cell tiles 0..3 and the operand of cell 224
+    constexpr int OFF = decltype(mc)::value * 64;
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) asm volatile("ds_read_b128 %0, %1" : "=v"(fbA[pt]) : "v"(bb[pt] ^ (uint32_t)(m << 6)));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(lx) : "v"(lx32 ^ (uint32_t)(m << 6)));
+    for (int pt = 0; pt < 4; ++pt) dsr128<OFF>(fbA[pt], bb[pt]);
+    dsr128<OFF>(lx, lx32);
   };
-  auto loadB = [&](int m) {  // 3 LDS reads: cell tiles 4..6
+  auto loadB = [&](auto mc) {  // 3 LDS reads: cell tiles 4..6
+    constexpr int OFF = decltype(mc)::value * 64;
 #pragma unroll
-    for (int pt = 0; pt < 3; ++pt) asm volatile("ds_read_b128 %0, %1" : "=v"(fbB[pt]) : "v"(bb[4 + pt] ^ (uint32_t)(m << 6)));
+    for (int pt = 0; pt < 3; ++pt) dsr128<OFF>(fbB[pt], bb[4 + pt]);
   };
-  set_tap_A(0);
-  set_tap_B(0);
-  loadA(0);
-#pragma unroll 1
-  for (int kk = 0; kk < KSTEPS; kk += 2) {
+  // One k-step.  M = k-step of the tap, S = the weight register set that holds its weights.  FOUR sets in rotation: at k-step k
+  // the weights of k-step k + 3 are requested into set (S + 3) % 4, so a request has three k-steps (about 10 k cycles with the
+  // partner wave on the pipe) to come back from L2 -- with one k-step of cover 5 % of the launch was exposed weight latency
+  // (measured with a build that reads the same weights every k-step, -DAZ_F32_WSAME).  A layer of 9 KS16 = 36 or 72 k-steps
+  // leaves the rotation where it found it and requests the next layer's k-steps 0..2 during its last three.  The stem has 9:
+  // its last three k-steps request the next layer's k-steps 1..3 (into sets 1..3) and k-step 0 follows after its last MFMAs,
+  // under the epilogue and the barriers between the layers.
+  constexpr int KSTEPS = 9 * KS16, NEXT_SHIFT = KSTEPS % 4;
+  static_assert(NEXT_SHIFT == 0 || NEXT_SHIFT == 1, "36, 72 or 9 k-steps");
+  auto step = [&](int tap, auto mc, auto sc) {
+    constexpr int M = decltype(mc)::value, S = decltype(sc)::value, V = (S + 3) % 4;
+    constexpr bool TAP_END = M == KS16 - 1;
+    const bool last = TAP_END && tap == 8;
+    {
+      const int kn = tap * KS16 + M + 3;
+      const bool own = kn < KSTEPS;
+      wload<CW>(wf[V], own ? wg : wnext, woff, cto, own ? kn : kn - KSTEPS + NEXT_SHIFT);
+    }
+    loadB(mc);
+    asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");  // group A of this k-step has returned
+    __builtin_amdgcn_sched_barrier(0);
+    if (LEFT) {  // cell 224, output channel 16 wave + r: that row of the weights IS this lane's a0 (see WFrag)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int k = kk + u;
-      if (k >= KSTEPS) break;
-      const bool last = k + 1 >= KSTEPS;
-      // the next k-step's weights (the next layer's first, at the end): in flight under this k-step's 56 MFMAs
-      if (!last) wload<CW>(wf[(u + 1) & 1], wg, woff, loff, k + 1);
-      else if (wnext != nullptr) wload<CW>(wf[(u + 1) & 1], wnext, woff, loff, 0);
-      loadB(k % KS16);
-      asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");  // group A of this k-step has returned
-      __builtin_amdgcn_sched_barrier(0);
-      if (LEFT) {
+      for (int t = 0; t < 4; ++t) lc = fmaf(wf[S].a0[t], lx[t], lc);
+      // (pins the sum HERE: left alone, the optimiser sinks the four k-steps' fmafs of a tap to the end of the loop body, which keeps
+      // every weight set alive across the requests that refill it -- copies, and a wait for all of them, at the end of each tap)
+      asm volatile("" : "+v"(lc));
+    }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) lc = fmaf(wf[u].l[t], lx[t], lc);
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        acc[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a0[t], fbA[pt][t], acc[pt][0], 0, 0, 0);
+        acc[pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a1[t], fbA[pt][t], acc[pt][1], 0, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-          acc[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].a0[t], fbA[pt][t], acc[pt][0], 0, 0, 0);
-          acc[pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].a1[t], fbA[pt][t], acc[pt][1], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAP_END) {
       if (!last) {
-        if ((k + 1) % KS16 == 0) set_tap_A((k + 1) / KS16);
-        loadA((k + 1) % KS16);
+        set_tap_A(tap + 1);
+        loadA(std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");  // group B of this k-step has returned
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (!last && (k + 1) % KS16 == 0) set_tap_B((k + 1) / KS16);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int pt = 0; pt < 3; ++pt) {
-          acc[4 + pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].a0[t], fbB[pt][t], acc[4 + pt][0], 0, 0, 0);
-          acc[4 + pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u].a1[t], fbB[pt][t], acc[4 + pt][1], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      loadA(std::integral_constant<int, M + 1>{});
+      asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAP_END) {
+      if (!last) set_tap_B();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt) {
+        acc[4 + pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a0[t], fbB[pt][t], acc[4 + pt][0], 0, 0, 0);
+        acc[4 + pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a1[t], fbB[pt][t], acc[4 + pt][1], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  set_tap_A(0);
+  set_tap_B();
+  loadA(std::integral_constant<int, 0>{});
+  using I0 = std::integral_constant<int, 0>;
+  if constexpr (KS16 == 1) {  // the stem: four taps (= four k-steps) per iteration, then tap 8
+#pragma unroll 1
+    for (int t4 = 0; t4 < 8; t4 += 4) static_for<4>([&](auto jc) { step(t4 + decltype(jc)::value, I0{}, jc); });
+    step(8, I0{}, I0{});
+    wload<CW>(wf[0], wnext, woff, cto, 0);
+  } else {
+    static_assert(KS16 % 4 == 0, "a tap leaves the four weight sets where it found them");
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap)
+      static_for<KS16>([&](auto mc) { step(tap, mc, std::integral_constant<int, decltype(mc)::value % 4>{}); });
   }
 }
 
@@ -503,7 +554,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
                                                           const float *__restrict__ headb, float *__restrict__ feat, int FS,
                                                           unsigned int *tickets) {
   constexpr int N = 15, NV = 225, WC = 8, SWB = 16, RGW = 8 * SWB, LCELL = 224, KP = 240;
-  constexpr int C = CW, ROW = 4 * CW, NW = CW / 16, NTH = 64 * NW, NCQ = CW / 32;  // waves; channel groups of 32
+  constexpr int C = CW, ROW = T16_ROW<CW>, NW = CW / 16, NTH = 64 * NW, NCQ = CW / 32;  // padded row bytes; waves; channel groups of 32
   constexpr int ACT_BYTES = NV * ROW + ROW, HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16, RG_BYTES = ((RGW + 4) * 4 + 15) / 16 * 16;
   constexpr int KSB16 = 4 * C * 16;
   extern __shared__ __attribute__((aligned(1024))) char smem_t16[];  // (conv_layer16g XORs chunk bits into finished addresses)
@@ -514,9 +565,9 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
   float *hp = (float *)((char *)rg + RG_BYTES);         // [NCQ channel groups][3 heads][225 cells]: partial head sums
   float *lh = hp + NCQ * 3 * NV + 2;                    // [NW waves][3]: head sums of cell 224
   float *bl = lh + 3 * NW;                                  // [(1 + L)][64]: every layer's bias (L <= T16_MAX_LAYERS)
-  auto act_addr = [](int p, int chunk) { return p * (4 * CW) + ((chunk ^ (p & 15)) << 4); };
+  auto act_addr = [](int p, int chunk) { return p * T16_ROW<CW> + (chunk << 4); };  // padded rows, no swizzle (conv_layer16g)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kq = lane >> 4, ch = wave >> 1, chalf = wave & 1;
+  const int kq = lane >> 4, ch = wave >> 1, chalf = wave & 1, cto = wave & 1;  // cto: accumulator tile ct holds channel tile 2 ch + (ct ^ cto)
 
   for (int i = tid; i < ACT_BYTES / 16; i += NTH) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero row
   for (int i = tid; i < 3 * C + 3; i += NTH) hw[i] = i < 3 * C ? headw[i] : headb[i - 3 * C];
@@ -533,8 +584,13 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       if (rr >= 0 && rr < N && cc >= 0 && cc < N) vm |= 1ull << (7 * t + pt);
     }
   }
-  WFrag wf[2];  // weight fragments of the running and the next k-step (global -> registers, one k-step ahead)
-  wload<CW>(wf[0], w0, (uint32_t)(kq * (C * 16) + (ch * 32 + (lane & 15)) * 16), (uint32_t)(kq * (C * 16) + (wave * 16 + (lane & 15)) * 16), 0);  // the stem's first
+  WFrag wf[4];  // weight fragments of the running k-step and the three after it (global -> registers, three k-steps ahead)
+  {
+    const uint32_t woff0 = (uint32_t)(kq * (C * 16) + (ch * 32 + (lane & 15)) * 16);
+    wload<CW>(wf[0], w0, woff0, cto, 0);  // the stem's first three k-steps
+    wload<CW>(wf[1], w0, woff0, cto, 1);
+    wload<CW>(wf[2], w0, woff0, cto, 2);
+  }
   // Boards are handed out by the ticket counter.  The NEXT board is looked up while the current one is computed, in steps
   // that are never waited for: the returning atomic is issued at the top of the board; after the stem thread 0 reads the
   // ticket's flag byte; before the first block's barrier it publishes the slot (or -2: flagged off, look again at the
@@ -611,7 +667,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     auto init = [&](const float *b, bool with_res) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const f32x4 bv = *(const f32x4 *)(b + ch * 32 + ct * 16 + kq * 4);
+        const f32x4 bv = *(const f32x4 *)(b + ch * 32 + (ct ^ cto) * 16 + kq * 4);
 #pragma unroll
         for (int pt = 0; pt < 7; ++pt) acc[pt][ct] = with_res ? bv + res[pt][ct] : bv;
       }
@@ -630,13 +686,13 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[pt][ct][j], 0.0f);
-          *(f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + ct) * 4 + kq)) = v;
+          *(f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + (ct ^ cto)) * 4 + kq)) = v;
         }
       if (kq == 0) *lptr = fmaxf(lc, 0.0f);
     };
     // ---- stem
     init(bl, false);
-    conv_layer16g<9, 1, true, CW>(act, w0, L > 0 ? wl : w0, wave, lane, pp0, vm, acc, lc, wf);  // (nine k-steps: the prefetch lands in wf[1])
+    conv_layer16g<1, true, CW>(act, w0, L > 0 ? wl : w0, wave, lane, pp0, vm, acc, lc, wf);  // (nine k-steps: the prefetch lands in wf[1])
     lfinal(bl, false);
     FSTAMP(3);
     if (L > 0) {
@@ -645,18 +701,17 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       __syncthreads();
     }
     FSTAMP(4);
-    wf[0] = wf[1];
     if (tid == 0 && ticket < G && flags != nullptr) pre_flag = flags[ticket];  // (consumed before the first block's barrier)
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
 #pragma unroll
       for (int pt = 0; pt < 7; ++pt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) res[pt][ct] = *(const f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + ct) * 4 + kq));
+        for (int ct = 0; ct < 2; ++ct) res[pt][ct] = *(const f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + (ct ^ cto)) * 4 + kq));
       lres = *lptr;
       init(bl + (1 + l) * C, false);
       FSTAMP(5 + 4 * l);
-      conv_layer16g<9 * (CW / 16), CW / 16, true, CW>(act, wl + (size_t)l * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc, wf);
+      conv_layer16g<CW / 16, true, CW>(act, wl + (size_t)l * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc, wf);
       lfinal(bl + (1 + l) * C, false);
       FSTAMP(6 + 4 * l);
       if (l == 0 && tid == 0) {  // publish the next board's slot
@@ -676,7 +731,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       init(bl + (2 + l) * C, true);
       FSTAMP(9 + 4 * l);
       if (l + 2 < L) {
-        conv_layer16g<9 * (CW / 16), CW / 16, true, CW>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 2) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc,
+        conv_layer16g<CW / 16, true, CW>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 2) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc,
                                    wf);
         lfinal(bl + (2 + l) * C, true);
         FSTAMP(10 + 4 * l);
@@ -686,7 +741,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
         __syncthreads();
         FSTAMP(12 + 4 * l);
       } else {  // the tower's last layer: its output stays in the accumulators for the heads; prefetch the next board's stem
-        conv_layer16g<9 * (CW / 16), CW / 16, true, CW>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, w0, wave, lane, pp0, vm, acc, lc, wf);
+        conv_layer16g<CW / 16, true, CW>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, w0, wave, lane, pp0, vm, acc, lc, wf);
         lfinal(bl + (2 + l) * C, true);
         FSTAMP(10 + 4 * l);
       }
@@ -701,7 +756,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       for (int ct = 0; ct < 2; ++ct) {
         f32x4 wv[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) wv[k] = *(const f32x4 *)(hw + k * C + ch * 32 + ct * 16 + kq * 4);
+        for (int k = 0; k < 3; ++k) wv[k] = *(const f32x4 *)(hw + k * C + ch * 32 + (ct ^ cto) * 16 + kq * 4);
 #pragma unroll
         for (int pt = 0; pt < 7; ++pt)
 #pragma unroll
@@ -935,7 +990,7 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
   };
   int rc;
   auto lds_t16 = [](int cw) -> size_t {  // act + zero row, head filters, packed input, head partial sums, bias table
-    return (size_t)(226 * 4 * cw) + ((3 * cw + 3) * 4 + 15) / 16 * 16 + ((128 + 4) * 4 + 15) / 16 * 16 + ((cw / 32) * 3 * 225 + 2 + 3 * (cw / 16)) * 4 +
+    return (size_t)(226 * (4 * cw + 16)) + ((3 * cw + 3) * 4 + 15) / 16 * 16 + ((128 + 4) * 4 + 15) / 16 * 16 + ((cw / 32) * 3 * 225 + 2 + 3 * (cw / 16)) * 4 +
            (size_t)(1 + T16_MAX_LAYERS) * cw * 4;
   };
   static const bool use32 = getenv("AZ_TOWER_F32_TILE32") != nullptr;  // diagnostic: the 32-cell-tile kernel on 15x15 too

@@ -17,6 +17,18 @@ if __name__ == "__main__":
     lib = C.CDLL(os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "alphazero_amd/lib/dev/f32stamp.so"))
     lib.az_tower_forward_f32.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]
     P = lambda t: C.c_void_p(t.data_ptr())
+    if os.environ.get("TIME"):  # launch time only (any build of the library): TIME=1 python scripts/dev/f32_stamp.py path/to/lib.so
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = int(os.environ.get("REPS", "60"))
+        for i in range(reps + 5):
+            if i == 5:
+                e0.record()
+            lib.az_tower_forward_f32(15, 64, B, ev.n_layers, P(x), None, None, None, P(ev.w0), P(ev.wl), P(ev.bias), P(ev.headw), P(ev.headb),
+                                     P(feat), ev.feat_stride, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"{sys.argv[1] if len(sys.argv) > 1 else 'f32stamp'}: {e0.elapsed_time(e1) / reps:.3f} ms per launch of {B} boards")
+        sys.exit(0)
     for _ in range(int(os.environ.get("REPS", "60"))):
         lib.az_tower_forward_f32(15, 64, B, ev.n_layers, P(x), None, None, None, P(ev.w0), P(ev.wl), P(ev.bias), P(ev.headw), P(ev.headb),
                                  P(feat), ev.feat_stride, C.c_void_p(torch.cuda.current_stream().cuda_stream))
