@@ -416,6 +416,9 @@ __device__ __forceinline__ void wload(WFrag &w, const char *wg, uint32_t woff, i
   w.a1 = *(const f32x4 *)(base + (256 - cto * 256) + woff);
 }
 
+// an opaque copy: what is derived from it is computed where it is used, not hoisted out of the board loop and spilled
+__device__ __forceinline__ int fresh(int v) { asm volatile("" : "+v"(v)); return v; }
+
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int CNT, class F>
@@ -660,25 +663,31 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     __syncthreads();
     FSTAMP(2);
 
-    f32x4 acc[7][2], res[7][2];
+    f32x4 acc[7][2];
     float lc = 0.0f, lres = 0.0f;  // cell 224: output channel lco of this wave's 16, partial over this lane's k quarter
-    const int lco = wave * 16 + (lane & 15);
-    float *const lptr = (float *)(act + act_addr(LCELL, lco >> 2) + (lco & 3) * 4);
-    auto init = [&](const float *b, bool with_res) {
+    // Everything the phases between the conv layers need per lane (cell, k quarter, channel of cell 224, shuffle partners) is
+    // re-derived from a laundered copy of the lane index inside each phase: left to itself the compiler hoists ~40 such
+    // values out of the board loop, spills them, and reloads them right after a conv loop -- behind the weight requests in flight.
+    auto corner_ptr = [&](int ln) { const int c = wave * 16 + (ln & 15); return (float *)(act + act_addr(LCELL, c >> 2) + (c & 3) * 4); };
+    auto shx = [](float t, int mask, int ln) { return __int_as_float(__builtin_amdgcn_ds_bpermute((ln ^ mask) << 2, __float_as_int(t))); };
+    auto init = [&](const float *b) {
+      const int kq = fresh(lane) >> 4;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const f32x4 bv = *(const f32x4 *)(b + ch * 32 + (ct ^ cto) * 16 + kq * 4);
 #pragma unroll
-        for (int pt = 0; pt < 7; ++pt) acc[pt][ct] = with_res ? bv + res[pt][ct] : bv;
+        for (int pt = 0; pt < 7; ++pt) acc[pt][ct] = bv;
       }
       lc = 0.0f;
     };
     auto lfinal = [&](const float *b, bool with_res) {  // the four k quarters of cell 224, then bias (+ residual)
-      lc = lc + __shfl_xor(lc, 16, 64);
-      lc = lc + __shfl_xor(lc, 32, 64);
+      const int ln = fresh(lane), lco = wave * 16 + (ln & 15);
+      lc = lc + shx(lc, 16, ln);
+      lc = lc + shx(lc, 32, ln);
       lc = (with_res ? b[lco] + lres : b[lco]) + lc;
     };
     auto epilogue = [&]() {
+      const int ln = fresh(lane), kq = ln >> 4, pp0 = 7 * chalf * 16 + (ln & 15);
 #pragma unroll
       for (int pt = 0; pt < 7; ++pt)
 #pragma unroll
@@ -688,10 +697,36 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[pt][ct][j], 0.0f);
           *(f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + (ct ^ cto)) * 4 + kq)) = v;
         }
+      if (kq == 0) *corner_ptr(ln) = fmaxf(lc, 0.0f);
+    };
+    // The epilogue of a block's FIRST conv, fused with the accumulator init of its second: a lane overwrites exactly the
+    // activations it will need again as the block's residual, so it reads them here, just before it stores over them, and
+    // starts the next accumulators at bias + residual -- the residual never sits in registers across a conv layer (56 VGPRs
+    // that used to be live through the first conv; with them the kernel spilled and every reload waited behind the weight
+    // requests in flight).  Same arithmetic as before: acc = (bias + x) first, then the MFMA chain.
+    auto epilogue_res = [&](const float *bnext) {
+      const int ln = fresh(lane), kq = ln >> 4, pp0 = 7 * chalf * 16 + (ln & 15);
+      float *const lptr = corner_ptr(ln);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 bv = *(const f32x4 *)(bnext + ch * 32 + (ct ^ cto) * 16 + kq * 4);
+#pragma unroll
+        for (int pt = 0; pt < 7; ++pt) {
+          f32x4 *const p = (f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + (ct ^ cto)) * 4 + kq));
+          const f32x4 xr = *p;
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[pt][ct][j], 0.0f);
+          *p = v;
+          acc[pt][ct] = bv + xr;
+        }
+      }
+      lres = *lptr;  // (every lane of the four k quarters reads it before the quarter-0 lane stores)
       if (kq == 0) *lptr = fmaxf(lc, 0.0f);
+      lc = 0.0f;
     };
     // ---- stem
-    init(bl, false);
+    init(bl);
     conv_layer16g<1, true, CW>(act, w0, L > 0 ? wl : w0, wave, lane, pp0, vm, acc, lc, wf);  // (nine k-steps: the prefetch lands in wf[1])
     lfinal(bl, false);
     FSTAMP(3);
@@ -704,12 +739,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     if (tid == 0 && ticket < G && flags != nullptr) pre_flag = flags[ticket];  // (consumed before the first block's barrier)
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
-#pragma unroll
-      for (int pt = 0; pt < 7; ++pt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) res[pt][ct] = *(const f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + (ct ^ cto)) * 4 + kq));
-      lres = *lptr;
-      init(bl + (1 + l) * C, false);
+      init(bl + (1 + l) * C);
       FSTAMP(5 + 4 * l);
       conv_layer16g<CW / 16, true, CW>(act, wl + (size_t)l * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc, wf);
       lfinal(bl + (1 + l) * C, false);
@@ -720,7 +750,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       }
       __syncthreads();
       FSTAMP(7 + 4 * l);
-      epilogue();
+      epilogue_res(bl + (2 + l) * C);
       if (l == 0 && x == nullptr) {  // (slots[2] was written before the barrier above)
         const int gn = slots[2];
         pre_have = gn >= 0;
@@ -728,7 +758,6 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       }
       __syncthreads();
       FSTAMP(8 + 4 * l);
-      init(bl + (2 + l) * C, true);
       FSTAMP(9 + 4 * l);
       if (l + 2 < L) {
         conv_layer16g<CW / 16, true, CW>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 2) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc,
@@ -749,6 +778,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     // ---- heads: 1x1 convs + ReLU from the accumulators.  A lane holds 8 of its cell's channels (2 channel tiles x 4), the
     // four k-quarter groups of a wave hold the 32 channels of its half, the other half sits in wave ^ 2.
     {
+      const int ln = fresh(lane), kq = ln >> 4, pp0 = 7 * chalf * 16 + (ln & 15), lco = wave * 16 + (ln & 15);
       float hs[7][3];
 #pragma unroll
       for (int pt = 0; pt < 7; ++pt) hs[pt][0] = hs[pt][1] = hs[pt][2] = 0.0f;
@@ -772,8 +802,8 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
 #pragma unroll
         for (int k = 0; k < 3; ++k) {  // sum over the four k-quarter groups (same order on every lane of a cell)
           float t = hs[pt][k];
-          t = t + __shfl_xor(t, 16, 64);
-          t = t + __shfl_xor(t, 32, 64);
+          t = t + shx(t, 16, ln);
+          t = t + shx(t, 32, ln);
           hs[pt][k] = t;
         }
       FSTAMP(27);
@@ -783,8 +813,8 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
         for (int k = 0; k < 3; ++k) {
           float t = a * hw[k * C + lco];
 #pragma unroll
-          for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
-          if (lane == 0) lh[wave * 3 + k] = t;
+          for (int off = 8; off >= 1; off >>= 1) t = t + shx(t, off, ln);
+          if (ln == 0) lh[wave * 3 + k] = t;
         }
       }
 #pragma unroll
