@@ -6,19 +6,22 @@
 // the 1x1 head convs+BN+ReLU, then the heads' Linear layers), same structure of the kernel: one workgroup (4 waves) owns
 // one 15x15 board (three 9x9 boards) for the whole tower, activations resident in LDS, every conv an implicit GEMM
 //   D[co][cell] = sum_{tap, ci} W[co][tap][ci] * X[ci][cell + shift(tap)]
-// on v_mfma_f32_32x32x2_f32 (f32 operands, f32 accumulate: bit for bit a k-ordered fmaf chain; dense peak 157.3 TFLOP/s
-// = 1/16 of the bf16 rate, so the MFMA pipe -- not LDS, not the weight stream -- is what bounds this kernel by a wide margin).
+// on f32 MFMAs (f32 operands, f32 accumulate: bit for bit a k-ordered fmaf chain; dense peak 157.3 TFLOP/s = 1/16 of the
+// bf16 rate, so the MFMA pipe -- not LDS, not the weight stream -- bounds these kernels, and ordinary VALU instructions do
+// not execute under an f32 MFMA: every instruction that is not an MFMA is launch time).
 //
-// LDS: act[cell][64] f32, 256 B per cell, the sixteen 16-byte channel chunks of a cell XOR-swizzled with (cell & 15): the
-// 32 lanes of a cell tile hold 32 consecutive cells, a tap shifts all of them by the same amount, so the 16 lanes of a
-// ds_read_b128 group hit 16 different bank quads.  Taps that fall off the board read a 256-byte zero row.
-// One ds_read_b128 feeds FOUR MFMAs: the instruction wants A[co][k = lane>>5] / B[k = lane>>5][cell], one float each; a
-// lane of half h reads channels 8m + 4h .. 8m + 4h + 3 and MFMA t of "k-step" m takes element t, i.e. the k pair
-// {8m + t, 8m + 4 + t} -- any pairing works as long as weights and activations agree.
-// Weights: [tap][k-step][half][co 64][4 ci] f32 in global memory = the order the LDS stage holds them (a lane's A read is
-// 16 B at co * 16: conflict free), streamed 4 k-steps (8 KiB) at a time by LDS-DMA, double buffered, under the MFMAs.
-// Per wave: 2 cell tiles x 2 channel tiles of 32x32 = 64 accumulator registers; the layer is computed in place (outputs
-// wait in the accumulators until every wave has read the input); the block's residual stays in registers as f32.
+// Two kernels:
+//  * k_tower_f32_t16<CW> (15x15 boards, 64- or 128-channel trunks; the benchmark's kernel): v_mfma_f32_16x16x4_f32 on 14 tiles of
+//    16 cells + one cell on the VALU, padded linear activation rows, weights from L2 into four rotating register sets three
+//    k-steps ahead, one barrier per layer.  Described at its definition below.
+//  * k_tower_f32<N, BPW> (9x9 boards, three per workgroup; also the diagnostic / deep-tower fallback for 15x15):
+//    v_mfma_f32_32x32x2_f32 on 32-cell tiles.  LDS: act[cell][64] f32, 256 B per cell, the sixteen 16-byte channel chunks of a
+//    cell XOR-swizzled with (cell & 15) (conflict-free ds_read_b128; taps that fall off the board read a zero row).  One
+//    ds_read_b128 feeds FOUR MFMAs: the instruction wants A[co][k = lane>>5] / B[k = lane>>5][cell], one float each; a lane
+//    of half h reads channels 8m + 4h .. + 3 and MFMA t of k-step m takes element t, i.e. the k pair {8m + t, 8m + 4 + t} --
+//    any pairing works as long as weights and activations agree.  Weights [tap][k-step][half][co 64][4 ci] f32 streamed 4
+//    k-steps (8 KiB) at a time by LDS-DMA, double buffered, under the MFMAs; 2 cell tiles x 2 channel tiles of 32x32 per
+//    wave; in-place layers; the block's residual in registers.
 // Boards are handed out by the library's ticket counter (az_tower.hip); the input is the engine's packed leaf batch
 // (8 bitboards + player) or dense f32 planes.  C ABI at the bottom; declared in include/az_engine.h.
 #include <hip/hip_runtime.h>
@@ -365,12 +368,12 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32(const float *__restrict__ 
 // 15x15 boards: the same tower on v_mfma_f32_16x16x4_f32 with 16-cell tiles.  225 cells = 14 tiles of 16 + ONE cell, where
 // eight 32-cell tiles spend 12 % of the MFMA time on 31 padding cells.  Wave w owns cell tiles 7 (w & 1) .. + 6 and the 32
 // output channels 32 (w >> 1) .. + 31: 7 x 2 accumulator tiles of 16 x 16 (56 registers), 14 per wave, all waves equal.
-// Cell 224 (the corner, four taps on the board) is computed on the VALU from the weight stages that stream through LDS
-// anyway: wave w takes its output channels 16 w .. + 15 in the MFMA's own lane layout (lane = channel x k quarter), two
-// more ds_read_b128 and four fmaf per k-step, in the shadow of the MFMAs.
+// Cell 224 (the corner, four taps on the board) is computed on the VALU: wave w takes its output channels 16 w .. + 15 in the
+// MFMA's own lane layout (lane = channel x k quarter) -- exactly the rows its a0 weight fragment holds (WFrag) -- with one
+// more ds_read_b128 and four fmaf per k-step.
 // The instruction takes A[co][k = lane >> 4] / B[k = lane >> 4][cell = lane & 15]; a lane of k-quarter kq reads the 16
-// bytes of channels 16 m + 4 kq .. + 3 once and feeds four MFMAs (MFMA t: the k set {16 m + 4 kq' + t}).  Same packed
-// weights as k_tower_f32 ([tap][16-byte chunk of ci][co][4]).
+// bytes of channels 16 m + 4 kq .. + 3 once and feeds four MFMAs (MFMA t: the k set {16 m + 4 kq' + t}).  Weights packed
+// [tap][16-byte chunk of ci][co][4] f32, read straight from global memory (L2).
 // Diagnostic build only (-DAZ_F32_STAMP=1): s_memtime stamps of one steady-state board of workgroup 7, per wave, into a
 // buffer of their own (read back with az_debug_f32_stamps); the product build executes no stamp.
 #ifndef AZ_F32_STAMP
@@ -385,14 +388,14 @@ static __device__ unsigned long long g_f32_wg[1024 * 4];  // per workgroup: real
 #endif
 constexpr int T16_MAX_LAYERS = 40;  // bias rows the 16-cell-tile kernel keeps in LDS (deeper towers run on k_tower_f32)
 
-// One layer.  The weight fragments are read straight from global memory (L2-resident: 0.6 MB for the whole tower) into
-// registers, one k-step ahead of their MFMAs, not through an LDS stage shared by the workgroup: a staged layer needs a
-// workgroup barrier per stage (18 per layer) and LDS-DMA issues between the MFMAs; this way there is ONE barrier per layer
-// (the in-place epilogue must wait for every wave's reads) and nothing but fragment reads between MFMAs.  (Measured equal
-// within 1 % to the staged version, 8.34 vs 8.39 ms, with 14 KB less LDS.)  The activation fragments run half a k-step
-// ahead through two register groups that are re-used as soon as their MFMAs have been issued: group A = cell tiles 0..3 +
-// the operand of cell 224, group B = cell tiles 4..6; with every k-step's reads exposed the MFMA pipe idled 20 % of the
-// launch (the partner wave of the SIMD does not reliably cover them).
+// One layer.  The weight fragments are read straight from global memory (L2-resident: 0.6 MB for the whole 64-channel tower)
+// into registers, three k-steps ahead of their MFMAs (four register sets in rotation), not through an LDS stage shared by
+// the workgroup: a staged layer needs a workgroup barrier per stage (18 per layer) and LDS-DMA issues between the MFMAs;
+// this way there is ONE barrier per layer (the in-place epilogue must wait for every wave's reads) and nothing but fragment
+// reads between MFMAs.  The activation fragments run half a k-step ahead through two register groups that are re-used as
+// soon as their MFMAs have been issued: group A = cell tiles 0..3 + the operand of cell 224, group B = cell tiles 4..6; with
+// every k-step's reads exposed the MFMA pipe idled 20 % of the launch (the partner wave of the SIMD does not reliably cover
+// them).
 // A lane's weights of one k-step, for both 16-channel tiles of its wave's 32 channels.  ODD waves hold the tiles SWAPPED: a0 =
 // channels 32 ch + 16 .. + 31, a1 = 32 ch .. + 15 (accumulator tile ct of wave w is channel tile 2 ch + (ct ^ (w & 1))
 // everywhere in the kernel), so that a0's row is always channel 16 w + r -- the row cell 224's VALU sum needs: no third load.
