@@ -443,7 +443,8 @@ template <int KS16, bool LEFT, int CW>
 __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, const char *wnext, int wave, int lane, const int pp0,
                                               const unsigned long long vm, f32x4 (&acc)[7][2], float &lc, WFrag (&wf)[4]) {
   constexpr int N = 15, ROWP = T16_ROW<CW>, LCELL = 224;
-  const int kq = lane >> 4, r = lane & 15, ch = wave >> 1;
+  const int ln = fresh(lane);  // (per-lane addresses are formed here, per layer: hoisted 64-bit lane pointers were spilled across the loops)
+  const int kq = ln >> 4, r = ln & 15, ch = wave >> 1;
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
   const uint32_t woff = kq * (CW * 16) + (ch * 32 + r) * 16;  // row 32 ch + r; a0's row is channel 16 wave + r (tile cto of the pair), a1's the other tile
   const int cto = wave & 1;
@@ -561,14 +562,17 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
                                                           unsigned int *tickets) {
   constexpr int N = 15, NV = 225, WC = 8, SWB = 16, RGW = 8 * SWB, LCELL = 224, KP = 240;
   constexpr int C = CW, ROW = T16_ROW<CW>, NW = CW / 16, NTH = 64 * NW, NCQ = CW / 32;  // padded row bytes; waves; channel groups of 32
-  constexpr int ACT_BYTES = NV * ROW + ROW, HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16, RG_BYTES = ((RGW + 4) * 4 + 15) / 16 * 16;
+  constexpr int ACT_BYTES = NV * ROW + ROW, HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16, RGS = RGW + 4, RG_BYTES = (2 * RGS + 8) * 4;
   constexpr int KSB16 = 4 * C * 16;
   extern __shared__ __attribute__((aligned(1024))) char smem_t16[];  // (conv_layer16g XORs chunk bits into finished addresses)
   char *act = smem_t16;
   float *hw = (float *)(smem_t16 + ACT_BYTES);
-  uint32_t *rg = (uint32_t *)((char *)hw + HW_BYTES);  // RGW ring words, player, slot, ticket
-  int *slots = (int *)rg + RGW + 1;   // {this board's slot, its ticket (G = past the end), the slot looked up ahead}
-  float *hp = (float *)((char *)rg + RG_BYTES);         // [NCQ channel groups][3 heads][225 cells]: partial head sums
+  uint32_t *rgb = (uint32_t *)((char *)hw + HW_BYTES);  // two buffers of RGW ring words + the player word (RGS words apart)
+  // {this board's slot, its ticket (G = past the end), the slot looked up ahead (-1: past the end, -2: not looked up), the next
+  // ticket, that ticket's flag byte}: the look-ahead state lives HERE, not in registers of thread 0 that would have to survive
+  // the conv loops (the kernel runs at its VGPR budget: they were spilled, a scratch store and a forced wait each per board)
+  int *slots = (int *)rgb + 2 * RGS;
+  float *hp = (float *)((char *)rgb + RG_BYTES);        // [NCQ channel groups][3 heads][225 cells]: partial head sums
   float *lh = hp + NCQ * 3 * NV + 2;                    // [NW waves][3]: head sums of cell 224
   float *bl = lh + 3 * NW;                                  // [(1 + L)][64]: every layer's bias (L <= T16_MAX_LAYERS)
   auto act_addr = [](int p, int chunk) { return p * T16_ROW<CW> + (chunk << 4); };  // padded rows, no swizzle (conv_layer16g)
@@ -598,14 +602,12 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     wload<CW>(wf[2], w0, woff0, cto, 2);
   }
   // Boards are handed out by the ticket counter.  The NEXT board is looked up while the current one is computed, in steps
-  // that are never waited for: the returning atomic is issued at the top of the board; after the stem thread 0 reads the
-  // ticket's flag byte; before the first block's barrier it publishes the slot (or -2: flagged off, look again at the
-  // top); after that barrier 129 threads request the slot's packed input into a register each.
-  int ticket = (int)blockIdx.x;   // thread 0: the next ticket
-  int pre_slot = -2;              // thread 0: the next board's slot if already known (-1: past the end, -2: not looked up)
-  uint8_t pre_flag = 0;
-  uint32_t pre_word = 0;          // threads < 129: word tid of the next board's packed input
-  bool pre_have = false;          // (uniform) pre_word holds the input of slots[2]
+  // that are never waited for and hold no register across a conv loop: thread 0 draws the next ticket (a returning atomic)
+  // after the stem's conv loop and stores it two barriers later, then sends the ticket's flag byte into LDS by LDS-DMA; after
+  // the first block's first conv it publishes the slot (or -2: flagged off, look again at the top); after the next barrier
+  // 129 lanes send the slot's packed input by LDS-DMA into the input buffer the running board does not use.
+  if (tid == 0) { slots[2] = -2; slots[3] = (int)blockIdx.x; slots[4] = 0; }
+  int rsel = 0;  // (uniform) which of the two input buffers the running board expands
 
 #if AZ_F32_STAMP
   int it = 0;
@@ -617,33 +619,35 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     ++it;
 #endif
     FSTAMP(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead's LDS-DMA (next input words) has landed
     __syncthreads();
     if (tid == 0) {
-      if (pre_slot == -2) {  // not looked up ahead (first board, or the ticket drawn ahead was a terminal leaf)
+      int ps = slots[2], tk = slots[3];
+      if (ps == -2) {  // not looked up ahead (first board, no residual block, or the ticket drawn ahead was a terminal leaf)
         for (;;) {
-          const bool on = ticket < G && (flags == nullptr || flags[ticket] != 0);
-          if (on || ticket >= G) break;
-          ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));  // a terminal leaf: one more draw
+          const bool on = tk < G && (flags == nullptr || flags[tk] != 0);
+          if (on || tk >= G) break;
+          tk = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));  // a terminal leaf: one more draw
         }
-        pre_slot = ticket < G ? ticket : -1;
+        ps = tk < G ? tk : -1;
       }
-      slots[0] = pre_slot;
-      slots[1] = pre_slot < 0 ? G : pre_slot;
+      slots[0] = ps;
+      slots[1] = ps < 0 ? G : ps;
     }
     __syncthreads();
     if (slots[1] >= G) break;
     FSTAMP(1);
     const int g = slots[0];
-    if (tid == 0) { ticket = (int)(gridDim.x + atomicAdd(&tickets[0], 1u)); pre_slot = -2; }
     if (x == nullptr) {
-      if (pre_have && slots[2] == g) {
-        if (tid < RGW + 1) rg[tid] = pre_word;
+      if (__builtin_amdgcn_readfirstlane((int)(slots[2] == g)) != 0) {
+        rsel ^= 1;  // the look-ahead fetched this board's input into the other buffer
       } else {
-        for (int i = tid; i < RGW + 1; i += NTH) rg[i] = i < RGW ? ring[(size_t)g * RGW + i] : (uint32_t)leafrec[g].w;
+        uint32_t *rgw = rgb + rsel * RGS;
+        for (int i = tid; i < RGW + 1; i += NTH) rgw[i] = i < RGW ? ring[(size_t)g * RGW + i] : (uint32_t)leafrec[g].w;
       }
       __syncthreads();
     }
-    pre_have = false;
+    const uint32_t *rg = rgb + rsel * RGS;
     if (tid < NV) {
       const int cell = tid;
       float c[16];
@@ -731,6 +735,9 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     // ---- stem
     init(bl);
     conv_layer16g<1, true, CW>(act, w0, L > 0 ? wl : w0, wave, lane, pp0, vm, acc, lc, wf);  // (nine k-steps: the prefetch lands in wf[1])
+    // the next ticket: drawn here (a returning atomic), stored after the two barriers below -- in a register across no conv loop
+    unsigned int drawn = 0;
+    if (tid == 0) drawn = atomicAdd(&tickets[0], 1u);
     lfinal(bl, false);
     FSTAMP(3);
     if (L > 0) {
@@ -739,7 +746,17 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       __syncthreads();
     }
     FSTAMP(4);
-    if (tid == 0 && ticket < G && flags != nullptr) pre_flag = flags[ticket];  // (consumed before the first block's barrier)
+    if (tid == 0) {
+      const int tk = (int)(gridDim.x + drawn);
+      slots[2] = -2;  // (every thread has compared it with this board's slot, three barriers ago)
+      slots[3] = tk;
+      slots[4] = 0;
+      // the ticket's flag byte travels by LDS-DMA into slots[4]: read back after the first block's first conv, whose own
+      // wait-counts (requests return in order) have by then covered it
+      if (tk < G && flags != nullptr)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(flags + tk),
+                                         (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(slots + 4), 1, 0, 0);
+    }
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
       init(bl + (1 + l) * C);
@@ -748,16 +765,25 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       lfinal(bl + (1 + l) * C, false);
       FSTAMP(6 + 4 * l);
       if (l == 0 && tid == 0) {  // publish the next board's slot
-        pre_slot = ticket >= G ? -1 : ((flags == nullptr || pre_flag != 0) ? ticket : -2);
-        slots[2] = pre_slot;
+        const int tk = slots[3];
+        slots[2] = tk >= G ? -1 : ((flags == nullptr || (slots[4] & 0xFF) != 0) ? tk : -2);
       }
       __syncthreads();
       FSTAMP(7 + 4 * l);
       epilogue_res(bl + (2 + l) * C);
-      if (l == 0 && x == nullptr) {  // (slots[2] was written before the barrier above)
-        const int gn = slots[2];
-        pre_have = gn >= 0;
-        if (pre_have && tid < RGW + 1) pre_word = tid < RGW ? ring[(size_t)gn * RGW + tid] : (uint32_t)leafrec[gn].w;
+      if (l == 0 && x == nullptr && tid < 192) {  // (slots[2] was written before the barrier above)
+        // the next board's packed input, by LDS-DMA into the buffer the running board does not use (waves 0 and 1: the 128
+        // ring words, lane 0 of wave 2: the player word); waited for at the top of the next board
+        const int gn = __builtin_amdgcn_readfirstlane(slots[2]);
+        if (gn >= 0) {
+          uint32_t *dst = rgb + (rsel ^ 1) * RGS;
+          if (wave < 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ring + (size_t)gn * RGW + tid),
+                                             (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(dst + wave * 64), 4, 0, 0);
+          else if (tid == 128)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)&leafrec[gn].w,
+                                             (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(dst + RGW), 4, 0, 0);
+        }
       }
       __syncthreads();
       FSTAMP(8 + 4 * l);
@@ -1023,7 +1049,7 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
   };
   int rc;
   auto lds_t16 = [](int cw) -> size_t {  // act + zero row, head filters, packed input, head partial sums, bias table
-    return (size_t)(226 * (4 * cw + 16)) + ((3 * cw + 3) * 4 + 15) / 16 * 16 + ((128 + 4) * 4 + 15) / 16 * 16 + ((cw / 32) * 3 * 225 + 2 + 3 * (cw / 16)) * 4 +
+    return (size_t)(226 * (4 * cw + 16)) + ((3 * cw + 3) * 4 + 15) / 16 * 16 + (2 * (128 + 4) + 8) * 4 + ((cw / 32) * 3 * 225 + 2 + 3 * (cw / 16)) * 4 +
            (size_t)(1 + T16_MAX_LAYERS) * cw * 4;
   };
   static const bool use32 = getenv("AZ_TOWER_F32_TILE32") != nullptr;  // diagnostic: the 32-cell-tile kernel on 15x15 too
