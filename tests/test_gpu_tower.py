@@ -229,3 +229,55 @@ def test_zero_block_tower_packed_flags_many_tickets(precision, board, G):
         assert int(touched.sum()) == G  # no terminal leaves this early: every slot is flagged
         assert torch.equal(p2, p1) and torch.equal(v2, v1)
     eng.check()
+
+
+@pytest.mark.parametrize("ch,blocks", [(64, 2), (64, 0), (128, 1)])
+def test_f32_tower_lookahead_under_random_flags(ch, blocks):
+    """The 15x15 f32 tower hands boards out by ticket and looks the next board up under the running one (ticket, flag byte and
+    packed input by LDS-DMA into a second buffer).  Synthetic packed batches with every kind of flag pattern -- dense, sparse,
+    long runs of terminal leaves, only the last slot on, nothing on -- must give, on the flagged rows, exactly the features
+    of the dense route, and leave the other rows alone."""
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(11)
+    G, n = 2100, 15
+    net = _randomised(GomokuNet(n, ch, blocks)).eval().cuda()
+    ev = FusedTowerEvaluator(net, "f32")
+    gen = torch.Generator().manual_seed(5)
+    stones = torch.randint(-1, 2, (G, 8, n * n), generator=gen)          # 8 history states per slot
+    player = torch.randint(0, 2, (G,), generator=gen) * 2 - 1
+    # packed form: per state 8 words of player-1 bits then 8 words of player-2 bits; leaf record .w = player to move
+    bits = torch.zeros(G, 8, 2, 256, dtype=torch.int64)
+    bits[:, :, 0, :225] = (stones == 1).long()
+    bits[:, :, 1, :225] = (stones == -1).long()
+    w = (bits.view(G, 8, 2, 8, 32) << torch.arange(32)).sum(-1)        # (G, 8, 2, 8) 32-bit words
+    ring = w.view(G, 128).to(torch.int64).cuda()
+    ring = (ring & 0xFFFFFFFF).to(torch.int64)
+    ring32 = torch.where(ring >= 2 ** 31, ring - 2 ** 32, ring).to(torch.int32).contiguous()
+    leaf = torch.zeros(G, 4, dtype=torch.int32)
+    leaf[:, 3] = player.int()
+    leaf = leaf.cuda()
+    x = torch.cat([stones.view(G, 8, n, n).float(), player.view(G, 1, 1, 1).float().expand(G, 1, n, n)], 1).cuda().contiguous()
+    pd, vd = ev(x)
+    pd, vd = pd.clone(), vd.clone().view(-1)
+    patterns = {
+        "all": torch.ones(G, dtype=torch.uint8),
+        "half": (torch.rand(G, generator=gen) < 0.5).to(torch.uint8),
+        "sparse": (torch.rand(G, generator=gen) < 0.03).to(torch.uint8),
+        "runs": ((torch.arange(G) // 97) % 2).to(torch.uint8),
+        "last_only": torch.zeros(G, dtype=torch.uint8).index_fill_(0, torch.tensor([G - 1]), 1),
+        "first_only": torch.zeros(G, dtype=torch.uint8).index_fill_(0, torch.tensor([0]), 1),
+        "none": torch.zeros(G, dtype=torch.uint8),
+    }
+    for name, fl in patterns.items():
+        flg = fl.cuda()
+        logits = torch.full((G, n * n), 77.0, device="cuda")
+        ev._buf[G][2].fill_(55.0)
+        _, v = ev(None, logits_out=logits, packed=(ring32.data_ptr(), leaf.data_ptr(), None, None, flg.data_ptr()), n_boards=G)
+        torch.cuda.synchronize()
+        on = flg.bool()
+        assert torch.equal(logits[on], pd[on]), name
+        assert torch.equal(v.view(-1)[on], vd[on]), name
+        # (the heads kernel evaluates every row of the feature buffer: rows that are off keep stale FEATURES, so only the
+        # flagged rows are specified; what must hold is that they equal the dense route bit for bit)
