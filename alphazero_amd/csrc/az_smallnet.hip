@@ -13,7 +13,7 @@
 //   (f32 operands, f32 accumulate: the reference's arithmetic; a lane of k-quarter kq reads the 16 bytes of channels
 //   16 m + 4 kq .. + 3 once and feeds four MFMAs); wave w owns output channels 16 w .. + 15 for all four 16-cell tiles;
 //   a tap that leaves the board (or the tile's own board) reads a zero row; weights come straight from global memory
-//   (L2), [tap][16-byte chunk of ci][co 64][4 ci] f32, one k-step ahead;
+//   (L2), [tap][16-byte chunk of ci][co 64][4 ci] f32, three k-steps ahead (four registers in rotation);
 //   tic-tac-toe's Linear(576 -> 128 | 64) is one more MFMA GEMM over the flattened conv output (boards as columns, the
 //   192 hidden units as rows, k = (cell, channel) with the weights permuted to that order by the host); everything
 //   smaller (1x1 head convs, the last Linear layers, tanh) is VALU work on LDS operands.
@@ -69,8 +69,12 @@ __device__ __forceinline__ void conv3x3(const char *src, const char *__restrict_
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = bv;
   }
-  f32x4 wa = *(const f32x4 *)wlane;  // k-step 0; every later one is requested one k-step ahead
-#pragma unroll 1
+  // weights: four registers in rotation, requested three k-steps ahead (everything unrolled: the compiler counts the waits)
+  constexpr int NK = 9 * KS;
+  f32x4 wq[4];
+#pragma unroll
+  for (int i = 0; i < 3 && i < NK; ++i) wq[i] = *(const f32x4 *)(wlane + (size_t)i * (4 * C * 16));
+#pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int d = (tap / 3 - 1) * W + (tap % 3 - 1);
     int q[4];
@@ -79,7 +83,8 @@ __device__ __forceinline__ void conv3x3(const char *src, const char *__restrict_
 #pragma unroll
     for (int m = 0; m < KS; ++m) {
       const int kk = tap * KS + m;
-      const f32x4 wn = *(const f32x4 *)(wlane + (size_t)(kk + 1 < 9 * KS ? kk + 1 : kk) * (4 * C * 16));
+      if (kk + 3 < NK) wq[(kk + 3) & 3] = *(const f32x4 *)(wlane + (size_t)(kk + 3) * (4 * C * 16));
+      const f32x4 wa = wq[kk & 3];
       f32x4 xb[4];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
@@ -88,7 +93,6 @@ __device__ __forceinline__ void conv3x3(const char *src, const char *__restrict_
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], xb[ct][t], acc[ct], 0, 0, 0);
-      wa = wn;
     }
   }
   // acc[ct][j] = channel 16 w + 4 kq + j of cell 16 ct + r
@@ -177,21 +181,26 @@ __global__ __launch_bounds__(256) void k_smallnet_f32(const float *__restrict__ 
     for (int nt = 0; nt < 3; ++nt) acc[nt] = *(const f32x4 *)(b1h + wave * 48 + nt * 16 + kq * 4);
     const int rowbase = r < TB ? r * HW : -1;  // column b = r of the GEMM: board r of the tile
     const char *wlane = W1 + (size_t)kq * (192 * 16) + (wave * 48 + r) * 16;
-#pragma unroll 1
-    for (int pos = 0; pos < HW; ++pos) {
+    // 36 k-steps, unrolled; the weight fragments (three per k-step) run two k-steps ahead through three register sets
+    constexpr int NKH = HW * 4;
+    f32x4 wq[3][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) wq[i][nt] = *(const f32x4 *)(wlane + (size_t)i * (4 * 192 * 16) + nt * 256);
+#pragma unroll
+    for (int ks = 0; ks < NKH; ++ks) {
+      const int pos = ks >> 2, m = ks & 3;
       const int row = rowbase >= 0 ? rowbase + pos : ZROW;
+      if (ks + 2 < NKH) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const f32x4 xb = *(const f32x4 *)(act2 + act_addr(row, 4 * m + kq));
-        const char *wk = wlane + (size_t)(pos * 4 + m) * (4 * 192 * 16);
-        f32x4 wa[3];
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt) wa[nt] = *(const f32x4 *)(wk + nt * 256);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int nt = 0; nt < 3; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][t], xb[t], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < 3; ++nt) wq[(ks + 2) % 3][nt] = *(const f32x4 *)(wlane + (size_t)(ks + 2) * (4 * 192 * 16) + nt * 256);
       }
+      const f32x4 xb = *(const f32x4 *)(act2 + act_addr(row, 4 * m + kq));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[ks % 3][nt][t], xb[t], acc[nt], 0, 0, 0);
     }
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {  // acc[nt][j] = hidden unit 48 w + 16 nt + 4 kq + j of board r
