@@ -4,18 +4,19 @@
 // this is the evaluator at the reference's own precision; az_tower.hip is the bf16 throughput version of the same tower.
 // Same network family (examples/gomoku/model.py:41-90: conv3x3(9->64)+BN+ReLU, residual blocks of two conv3x3(64->64)+BN,
 // the 1x1 head convs+BN+ReLU, then the heads' Linear layers), same structure of the kernel: one workgroup (4 waves) owns
-// one 15x15 board (three 9x9 boards) for the whole tower, activations resident in LDS, every conv an implicit GEMM
+// one board (the 32-cell-tile kernel: three 9x9 boards) for the whole tower, activations resident in LDS, every conv an implicit GEMM
 //   D[co][cell] = sum_{tap, ci} W[co][tap][ci] * X[ci][cell + shift(tap)]
 // on f32 MFMAs (f32 operands, f32 accumulate: bit for bit a k-ordered fmaf chain; dense peak 157.3 TFLOP/s = 1/16 of the
 // bf16 rate, so the MFMA pipe -- not LDS, not the weight stream -- bounds these kernels, and ordinary VALU instructions do
 // not execute under an f32 MFMA: every instruction that is not an MFMA is launch time).
 //
 // Two kernels:
-//  * k_tower_f32_t16<CW> (15x15 boards, 64- or 128-channel trunks; the benchmark's kernel): v_mfma_f32_16x16x4_f32 on 14 tiles of
-//    16 cells + one cell on the VALU, padded linear activation rows, weights from L2 into four rotating register sets three
-//    k-steps ahead, one barrier per layer.  Described at its definition below.
-//  * k_tower_f32<N, BPW> (9x9 boards, three per workgroup; also the diagnostic / deep-tower fallback for 15x15):
-//    v_mfma_f32_32x32x2_f32 on 32-cell tiles.  LDS: act[cell][64] f32, 256 B per cell, the sixteen 16-byte channel chunks of a
+//  * k_tower_f32_t16<CW, N> (15x15 boards with 64- or 128-channel trunks -- the benchmark's kernel -- and 9x9 boards with 64):
+//    v_mfma_f32_16x16x4_f32 on tiles of 16 cells (225 = 14 tiles + one cell, 81 = 5 tiles + one cell: the odd cell on the VALU),
+//    padded linear activation rows, weights from L2 into four rotating register sets three k-steps ahead, one barrier per
+//    layer.  Described at its definition below.
+//  * k_tower_f32<N, BPW> (towers deeper than T16_MAX_LAYERS conv layers, and the diagnostic AZ_TOWER_F32_TILE32=1; 9x9 boards
+//    three per workgroup): v_mfma_f32_32x32x2_f32 on 32-cell tiles.  LDS: act[cell][64] f32, 256 B per cell, the sixteen 16-byte channel chunks of a
 //    cell XOR-swizzled with (cell & 15) (conflict-free ds_read_b128; taps that fall off the board read a zero row).  One
 //    ds_read_b128 feeds FOUR MFMAs: the instruction wants A[co][k = lane>>5] / B[k = lane>>5][cell], one float each; a lane
 //    of half h reads channels 8m + 4h .. + 3 and MFMA t of k-step m takes element t, i.e. the k pair {8m + t, 8m + 4 + t} --
@@ -371,6 +372,9 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32(const float *__restrict__ 
 // Cell 224 (the corner, four taps on the board) is computed on the VALU: wave w takes its output channels 16 w .. + 15 in the
 // MFMA's own lane layout (lane = channel x k quarter) -- exactly the rows its a0 weight fragment holds (WFrag) -- with one
 // more ds_read_b128 and four fmaf per k-step.
+// 9x9 boards (T16Geo below): 81 cells = 5 tiles + cell 80; every wave takes all five cell tiles and ONE channel tile (wave w =
+// channels 16 w .. + 15, its a0 fragment; no a1): 20 accumulator registers, 128 VGPRs, four workgroups per CU (measured:
+// 0.80 ms per 4,096 boards with 4, 0.84 with 3, 0.82 with 2 workgroups per CU; the 32-cell-tile kernel: 0.91).
 // The instruction takes A[co][k = lane >> 4] / B[k = lane >> 4][cell = lane & 15]; a lane of k-quarter kq reads the 16
 // bytes of channels 16 m + 4 kq .. + 3 once and feeds four MFMAs (MFMA t: the k set {16 m + 4 kq' + t}).  Weights packed
 // [tap][16-byte chunk of ci][co][4] f32, read straight from global memory (L2).
@@ -406,7 +410,21 @@ struct WFrag { f32x4 a0, a1; };
 // per tap and no conservative wait at the loop header, but the register allocator copies three of the four a0 fragments at
 // the end of every tap (loop-carried values), and a copy of a register whose load is still in flight reads stale data: the
 // compiler must know about these loads.)
-template <int CW>
+// Geometry of the 16-cell-tile kernel.  N*N = 16 k + 1 for both boards: 15x15 = 14 tiles + cell 224, 9x9 = 5 tiles + cell 80.
+//   15x15: the cell tiles are split over two groups of waves (7 each), a wave owns 2 channel tiles (32 channels);
+//   9x9:   every wave sees all 5 cell tiles and owns ONE channel tile (16 channels, wave w = channels 16 w .. + 15): 20
+//          accumulator registers, so twice as many workgroups per CU cover each other's barriers and between-layer phases.
+template <int CW, int N>
+struct T16Geo {
+  static constexpr int NV = N * N, LCELL = NV - 1, NSPLIT = N == 15 ? 2 : 1, NT = NV / 16 / NSPLIT, NCT = N == 15 ? 2 : 1;
+  static constexpr int NA = (NT + 1) / 2, NB = NT - NA;             // cell tiles of activation register groups A and B
+  static constexpr int NCG = CW / (16 * NCT), NW = NCG * NSPLIT;  // channel groups; waves
+  static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = 8 * SWB, KP = (NV + 15) / 16 * 16;
+  static constexpr int WG_PER_CU = CW == 128 ? 1 : (N == 15 ? 2 : 4);
+  static_assert(NV % 16 == 1 && (NV / 16) % NSPLIT == 0 && 9 * NT <= 64, "whole tiles + one cell; the tap mask fits 64 bits");
+};
+
+template <int CW, int NCT>
 __device__ __forceinline__ void wload(WFrag &w, const char *wg, uint32_t woff, int cto, int kk) {
   constexpr int KSBW = 4 * CW * 16;  // bytes of one k-step of 16 input channels: [kq 4][co CW][4] f32
 #ifdef AZ_F32_WSAME  // diagnostic build: every k-step reads k-step 0's weights (always cache hits; wrong results, timing only)
@@ -416,7 +434,7 @@ __device__ __forceinline__ void wload(WFrag &w, const char *wg, uint32_t woff, i
   // the scalar base: one 32-bit lane offset serves both loads
   const char *base = wg + (size_t)kk * KSBW;
   w.a0 = *(const f32x4 *)(base + cto * 256 + woff);
-  w.a1 = *(const f32x4 *)(base + (256 - cto * 256) + woff);
+  if constexpr (NCT == 2) w.a1 = *(const f32x4 *)(base + (256 - cto * 256) + woff);
 }
 
 // an opaque copy: what is derived from it is computed where it is used, not hoisted out of the board loop and spilled
@@ -439,41 +457,44 @@ __device__ __forceinline__ void dsr128(f32x4 &d, uint32_t a) { asm volatile("ds_
 // array that is otherwise 11 % busy.  The loop runs over taps; the k-steps of a tap are unrolled.
 template <int CW> constexpr int T16_ROW = 4 * CW + 16;
 
-template <int KS16, bool LEFT, int CW>
+template <int KS16, bool LEFT, int CW, int N>
 __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, const char *wnext, int wave, int lane, const int pp0,
-                                              const unsigned long long vm, f32x4 (&acc)[7][2], float &lc, WFrag (&wf)[4]) {
-  constexpr int N = 15, ROWP = T16_ROW<CW>, LCELL = 224;
+                                              const unsigned long long vm, f32x4 (&acc)[T16Geo<CW, N>::NT][T16Geo<CW, N>::NCT], float &lc,
+                                              WFrag (&wf)[4]) {
+  using Q = T16Geo<CW, N>;
+  constexpr int ROWP = T16_ROW<CW>, LCELL = Q::LCELL, NT = Q::NT, NCT = Q::NCT, NA = Q::NA, NB = Q::NB;
   const int ln = fresh(lane);  // (per-lane addresses are formed here, per layer: hoisted 64-bit lane pointers were spilled across the loops)
-  const int kq = ln >> 4, r = ln & 15, ch = wave >> 1;
+  const int kq = ln >> 4, r = ln & 15, cg = Q::NSPLIT == 2 ? wave >> 1 : wave;
   const uint32_t act32 = (uint32_t)(uintptr_t)act;
-  const uint32_t woff = kq * (CW * 16) + (ch * 32 + r) * 16;  // row 32 ch + r; a0's row is channel 16 wave + r (tile cto of the pair), a1's the other tile
-  const int cto = wave & 1;
-  uint32_t bb[7], lx32 = 0, tbase = 0, tmask = 0;
-  const uint32_t zaddr = act32 + (uint32_t)(225 * ROWP + (kq << 4));  // the zero row
-  auto set_tap_A = [&](int tap) {  // (bit 7 tap + pt of vm: that tap of cell pp0 + 16 pt is on the board)
+  // first row of the wave's channel group + r; a0's row is channel 16 wave + r (tile cto of a pair of tiles), a1's the other tile
+  const uint32_t woff = kq * (CW * 16) + (cg * (16 * NCT) + r) * 16;
+  const int cto = NCT == 2 ? wave & 1 : 0;
+  uint32_t bb[NT], lx32 = 0, tbase = 0, tmask = 0;
+  const uint32_t zaddr = act32 + (uint32_t)(Q::NV * ROWP + (kq << 4));  // the zero row
+  auto set_tap_A = [&](int tap) {  // (bit NT tap + pt of vm: that tap of cell pp0 + 16 pt is on the board)
     const int d = (tap / 3 - 1) * N + (tap % 3 - 1);
     tbase = act32 + (uint32_t)((pp0 + d) * ROWP + (kq << 4));  // ("negative" rows only occur masked, or with 16 pt rows added)
-    tmask = (uint32_t)(vm >> (7 * tap));
+    tmask = (uint32_t)(vm >> (NT * tap));
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWP) : zaddr;
+    for (int pt = 0; pt < NA; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWP) : zaddr;
     // cell 224: taps with dr <= 0 and dc <= 0 are on the board for that corner cell; the others read the zero row
     lx32 = (tap / 3 <= 1 && tap % 3 <= 1) ? act32 + (uint32_t)((LCELL + d) * ROWP + (kq << 4)) : zaddr;
   };
   auto set_tap_B = [&]() {  // (after set_tap_A of the same tap)
 #pragma unroll
-    for (int pt = 4; pt < 7; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWP) : zaddr;
+    for (int pt = NA; pt < NT; ++pt) bb[pt] = (tmask & (1u << pt)) ? tbase + (uint32_t)(16 * pt * ROWP) : zaddr;
   };
-  f32x4 fbA[4], fbB[3], lx;
-  auto loadA = [&](auto mc) {  // 5 LDS reads: cell tiles 0..3 and the operand of cell 224
+  f32x4 fbA[NA], fbB[NB], lx;
+  auto loadA = [&](auto mc) {  // NA + 1 LDS reads: cell tiles 0..NA-1 and the operand of the last cell
     constexpr int OFF = decltype(mc)::value * 64;
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) dsr128<OFF>(fbA[pt], bb[pt]);
+    for (int pt = 0; pt < NA; ++pt) dsr128<OFF>(fbA[pt], bb[pt]);
     dsr128<OFF>(lx, lx32);
   };
-  auto loadB = [&](auto mc) {  // 3 LDS reads: cell tiles 4..6
+  auto loadB = [&](auto mc) {  // NB LDS reads: cell tiles NA..NT-1
     constexpr int OFF = decltype(mc)::value * 64;
 #pragma unroll
-    for (int pt = 0; pt < 3; ++pt) dsr128<OFF>(fbB[pt], bb[4 + pt]);
+    for (int pt = 0; pt < NB; ++pt) dsr128<OFF>(fbB[pt], bb[NA + pt]);
   };
   // One k-step.  M = k-step of the tap, S = the weight register set that holds its weights.  FOUR sets in rotation: at k-step k
   // the weights of k-step k + 3 are requested into set (S + 3) % 4, so a request has three k-steps (about 10 k cycles with the
@@ -491,10 +512,10 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
     {
       const int kn = tap * KS16 + M + 3;
       const bool own = kn < KSTEPS;
-      wload<CW>(wf[V], own ? wg : wnext, woff, cto, own ? kn : kn - KSTEPS + NEXT_SHIFT);
+      wload<CW, NCT>(wf[V], own ? wg : wnext, woff, cto, own ? kn : kn - KSTEPS + NEXT_SHIFT);
     }
     loadB(mc);
-    asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");  // group A of this k-step has returned
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NB) : "memory");  // group A of this k-step has returned
     __builtin_amdgcn_sched_barrier(0);
     if (LEFT) {  // cell 224, output channel 16 wave + r: that row of the weights IS this lane's a0 (see WFrag)
 #pragma unroll
@@ -506,22 +527,22 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) {
+      for (int pt = 0; pt < NA; ++pt) {
         acc[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a0[t], fbA[pt][t], acc[pt][0], 0, 0, 0);
-        acc[pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a1[t], fbA[pt][t], acc[pt][1], 0, 0, 0);
+        if constexpr (NCT == 2) acc[pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a1[t], fbA[pt][t], acc[pt][1], 0, 0, 0);
       }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TAP_END) {
       if (!last) {
         set_tap_A(tap + 1);
         loadA(std::integral_constant<int, 0>{});
-        asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");  // group B of this k-step has returned
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA + 1) : "memory");  // group B of this k-step has returned
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     } else {
       loadA(std::integral_constant<int, M + 1>{});
-      asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NA + 1) : "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TAP_END) {
@@ -530,9 +551,9 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt) {
-        acc[4 + pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a0[t], fbB[pt][t], acc[4 + pt][0], 0, 0, 0);
-        acc[4 + pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a1[t], fbB[pt][t], acc[4 + pt][1], 0, 0, 0);
+      for (int pt = 0; pt < NB; ++pt) {
+        acc[NA + pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a0[t], fbB[pt][t], acc[NA + pt][0], 0, 0, 0);
+        if constexpr (NCT == 2) acc[NA + pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a1[t], fbB[pt][t], acc[NA + pt][1], 0, 0, 0);
       }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -544,7 +565,7 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
 #pragma unroll 1
     for (int t4 = 0; t4 < 8; t4 += 4) static_for<4>([&](auto jc) { step(t4 + decltype(jc)::value, I0{}, jc); });
     step(8, I0{}, I0{});
-    wload<CW>(wf[0], wnext, woff, cto, 0);
+    wload<CW, NCT>(wf[0], wnext, woff, cto, 0);
   } else {
     static_assert(KS16 % 4 == 0, "a tap leaves the four weight sets where it found them");
 #pragma unroll 1
@@ -553,15 +574,16 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
   }
 }
 
-template <int CW>
-__global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__restrict__ x, const uint32_t *__restrict__ ring,
+template <int CW, int N>
+__global__ __launch_bounds__((64 * T16Geo<CW, N>::NW), (T16Geo<CW, N>::WG_PER_CU == 1 ? 2 : T16Geo<CW, N>::WG_PER_CU)) void k_tower_f32_t16(const float *__restrict__ x, const uint32_t *__restrict__ ring,
                                                           const int4 *__restrict__ leafrec, const uint8_t *__restrict__ flags, int G,
                                                           const char *__restrict__ w0, const char *__restrict__ wl,
                                                           const float *__restrict__ bias, int L, const float *__restrict__ headw,
                                                           const float *__restrict__ headb, float *__restrict__ feat, int FS,
                                                           unsigned int *tickets) {
-  constexpr int N = 15, NV = 225, WC = 8, SWB = 16, RGW = 8 * SWB, LCELL = 224, KP = 240;
-  constexpr int C = CW, ROW = T16_ROW<CW>, NW = CW / 16, NTH = 64 * NW, NCQ = CW / 32;  // padded row bytes; waves; channel groups of 32
+  using Q = T16Geo<CW, N>;
+  constexpr int NV = Q::NV, WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, LCELL = Q::LCELL, KP = Q::KP, NT = Q::NT, NCT = Q::NCT;
+  constexpr int C = CW, ROW = T16_ROW<CW>, NW = Q::NW, NTH = 64 * NW, NCQ = Q::NCG;  // padded row bytes; waves; channel groups
   constexpr int ACT_BYTES = NV * ROW + ROW, HW_BYTES = ((3 * C + 3) * 4 + 15) / 16 * 16, RGS = RGW + 4, RG_BYTES = (2 * RGS + 8) * 4;
   constexpr int KSB16 = 4 * C * 16;
   extern __shared__ __attribute__((aligned(1024))) char smem_t16[];  // (conv_layer16g XORs chunk bits into finished addresses)
@@ -572,40 +594,41 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
   // ticket, that ticket's flag byte}: the look-ahead state lives HERE, not in registers of thread 0 that would have to survive
   // the conv loops (the kernel runs at its VGPR budget: they were spilled, a scratch store and a forced wait each per board)
   int *slots = (int *)rgb + 2 * RGS;
-  float *hp = (float *)((char *)rgb + RG_BYTES);        // [NCQ channel groups][3 heads][225 cells]: partial head sums
-  float *lh = hp + NCQ * 3 * NV + 2;                    // [NW waves][3]: head sums of cell 224
-  float *bl = lh + 3 * NW;                                  // [(1 + L)][64]: every layer's bias (L <= T16_MAX_LAYERS)
+  float *hp = (float *)((char *)rgb + RG_BYTES);        // [NCQ channel groups][3 heads][NV cells]: partial head sums
+  float *lh = hp + NCQ * 3 * NV;                        // [NW waves][3]: head sums of the last cell
+  float *bl = hp + (NCQ * 3 * NV + 3 * NW + 3) / 4 * 4;  // [(1 + L)][C]: every layer's bias (L <= T16_MAX_LAYERS), 16-byte aligned
   auto act_addr = [](int p, int chunk) { return p * T16_ROW<CW> + (chunk << 4); };  // padded rows, no swizzle (conv_layer16g)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kq = lane >> 4, ch = wave >> 1, chalf = wave & 1, cto = wave & 1;  // cto: accumulator tile ct holds channel tile 2 ch + (ct ^ cto)
+  // ch: the wave's channel group (NCT tiles of 16), chalf: its group of cell tiles; cto: accumulator tile ct holds channel tile NCT ch + (ct ^ cto)
+  const int kq = lane >> 4, ch = Q::NSPLIT == 2 ? wave >> 1 : wave, chalf = Q::NSPLIT == 2 ? wave & 1 : 0, cto = NCT == 2 ? wave & 1 : 0;
 
   for (int i = tid; i < ACT_BYTES / 16; i += NTH) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero row
   for (int i = tid; i < 3 * C + 3; i += NTH) hw[i] = i < 3 * C ? headw[i] : headb[i - 3 * C];
   for (int i = tid; i < (1 + L) * C; i += NTH) bl[i] = bias[i];
 
-  const int pp0 = 7 * chalf * 16 + (lane & 15);  // this lane's cells: pp0 + 16 pt
-  unsigned long long vm = 0;                      // bit 7 tap + pt: that tap of cell pp0 + 16 pt is on the board
+  const int pp0 = NT * chalf * 16 + (lane & 15);  // this lane's cells: pp0 + 16 pt
+  unsigned long long vm = 0;                       // bit NT tap + pt: that tap of cell pp0 + 16 pt is on the board
 #pragma unroll
-  for (int pt = 0; pt < 7; ++pt) {
+  for (int pt = 0; pt < NT; ++pt) {
     const int cell = pp0 + 16 * pt, row = cell / N, col = cell % N;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int rr = row + t / 3 - 1, cc = col + t % 3 - 1;
-      if (rr >= 0 && rr < N && cc >= 0 && cc < N) vm |= 1ull << (7 * t + pt);
+      if (rr >= 0 && rr < N && cc >= 0 && cc < N) vm |= 1ull << (NT * t + pt);
     }
   }
   WFrag wf[4];  // weight fragments of the running k-step and the three after it (global -> registers, three k-steps ahead)
   {
-    const uint32_t woff0 = (uint32_t)(kq * (C * 16) + (ch * 32 + (lane & 15)) * 16);
-    wload<CW>(wf[0], w0, woff0, cto, 0);  // the stem's first three k-steps
-    wload<CW>(wf[1], w0, woff0, cto, 1);
-    wload<CW>(wf[2], w0, woff0, cto, 2);
+    const uint32_t woff0 = (uint32_t)(kq * (C * 16) + (ch * (16 * NCT) + (lane & 15)) * 16);
+    wload<CW, NCT>(wf[0], w0, woff0, cto, 0);  // the stem's first three k-steps
+    wload<CW, NCT>(wf[1], w0, woff0, cto, 1);
+    wload<CW, NCT>(wf[2], w0, woff0, cto, 2);
   }
   // Boards are handed out by the ticket counter.  The NEXT board is looked up while the current one is computed, in steps
   // that are never waited for and hold no register across a conv loop: thread 0 draws the next ticket (a returning atomic)
   // after the stem's conv loop and stores it two barriers later, then sends the ticket's flag byte into LDS by LDS-DMA; after
   // the first block's first conv it publishes the slot (or -2: flagged off, look again at the top); after the next barrier
-  // 129 lanes send the slot's packed input by LDS-DMA into the input buffer the running board does not use.
+  // RGW + 1 lanes send the slot's packed input by LDS-DMA into the input buffer the running board does not use.
   if (tid == 0) { slots[2] = -2; slots[3] = (int)blockIdx.x; slots[4] = 0; }
   int rsel = 0;  // (uniform) which of the two input buffers the running board expands
 
@@ -648,8 +671,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       __syncthreads();
     }
     const uint32_t *rg = rgb + rsel * RGS;
-    if (tid < NV) {
-      const int cell = tid;
+    for (int cell = tid; cell < NV; cell += NTH) {
       float c[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) c[k] = 0.0f;
@@ -670,8 +692,8 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     __syncthreads();
     FSTAMP(2);
 
-    f32x4 acc[7][2];
-    float lc = 0.0f, lres = 0.0f;  // cell 224: output channel lco of this wave's 16, partial over this lane's k quarter
+    f32x4 acc[NT][NCT];
+    float lc = 0.0f, lres = 0.0f;  // the last cell (224 / 80): output channel lco of this wave's 16, partial over this lane's k quarter
     // Everything the phases between the conv layers need per lane (cell, k quarter, channel of cell 224, shuffle partners) is
     // re-derived from a laundered copy of the lane index inside each phase: left to itself the compiler hoists ~40 such
     // values out of the board loop, spills them, and reloads them right after a conv loop -- behind the weight requests in flight.
@@ -680,10 +702,10 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     auto init = [&](const float *b) {
       const int kq = fresh(lane) >> 4;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const f32x4 bv = *(const f32x4 *)(b + ch * 32 + (ct ^ cto) * 16 + kq * 4);
+      for (int ct = 0; ct < NCT; ++ct) {
+        const f32x4 bv = *(const f32x4 *)(b + (ch * NCT + (ct ^ cto)) * 16 + kq * 4);
 #pragma unroll
-        for (int pt = 0; pt < 7; ++pt) acc[pt][ct] = bv;
+        for (int pt = 0; pt < NT; ++pt) acc[pt][ct] = bv;
       }
       lc = 0.0f;
     };
@@ -694,15 +716,15 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       lc = (with_res ? b[lco] + lres : b[lco]) + lc;
     };
     auto epilogue = [&]() {
-      const int ln = fresh(lane), kq = ln >> 4, pp0 = 7 * chalf * 16 + (ln & 15);
+      const int ln = fresh(lane), kq = ln >> 4, pp0 = NT * chalf * 16 + (ln & 15);
 #pragma unroll
-      for (int pt = 0; pt < 7; ++pt)
+      for (int pt = 0; pt < NT; ++pt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < NCT; ++ct) {
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[pt][ct][j], 0.0f);
-          *(f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + (ct ^ cto)) * 4 + kq)) = v;
+          *(f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * NCT + (ct ^ cto)) * 4 + kq)) = v;
         }
       if (kq == 0) *corner_ptr(ln) = fmaxf(lc, 0.0f);
     };
@@ -712,14 +734,14 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     // that used to be live through the first conv; with them the kernel spilled and every reload waited behind the weight
     // requests in flight).  Same arithmetic as before: acc = (bias + x) first, then the MFMA chain.
     auto epilogue_res = [&](const float *bnext) {
-      const int ln = fresh(lane), kq = ln >> 4, pp0 = 7 * chalf * 16 + (ln & 15);
+      const int ln = fresh(lane), kq = ln >> 4, pp0 = NT * chalf * 16 + (ln & 15);
       float *const lptr = corner_ptr(ln);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const f32x4 bv = *(const f32x4 *)(bnext + ch * 32 + (ct ^ cto) * 16 + kq * 4);
+      for (int ct = 0; ct < NCT; ++ct) {
+        const f32x4 bv = *(const f32x4 *)(bnext + (ch * NCT + (ct ^ cto)) * 16 + kq * 4);
 #pragma unroll
-        for (int pt = 0; pt < 7; ++pt) {
-          f32x4 *const p = (f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * 2 + (ct ^ cto)) * 4 + kq));
+        for (int pt = 0; pt < NT; ++pt) {
+          f32x4 *const p = (f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * NCT + (ct ^ cto)) * 4 + kq));
           const f32x4 xr = *p;
           f32x4 v;
 #pragma unroll
@@ -734,7 +756,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     };
     // ---- stem
     init(bl);
-    conv_layer16g<1, true, CW>(act, w0, L > 0 ? wl : w0, wave, lane, pp0, vm, acc, lc, wf);  // (nine k-steps: the prefetch lands in wf[1])
+    conv_layer16g<1, true, CW, N>(act, w0, L > 0 ? wl : w0, wave, lane, pp0, vm, acc, lc, wf);  // (nine k-steps: the prefetch lands in wf[1])
     // the next ticket: drawn here (a returning atomic), stored after the two barriers below -- in a register across no conv loop
     unsigned int drawn = 0;
     if (tid == 0) drawn = atomicAdd(&tickets[0], 1u);
@@ -761,7 +783,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     for (int l = 0; l < L; l += 2) {
       init(bl + (1 + l) * C);
       FSTAMP(5 + 4 * l);
-      conv_layer16g<CW / 16, true, CW>(act, wl + (size_t)l * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc, wf);
+      conv_layer16g<CW / 16, true, CW, N>(act, wl + (size_t)l * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc, wf);
       lfinal(bl + (1 + l) * C, false);
       FSTAMP(6 + 4 * l);
       if (l == 0 && tid == 0) {  // publish the next board's slot
@@ -771,16 +793,18 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       __syncthreads();
       FSTAMP(7 + 4 * l);
       epilogue_res(bl + (2 + l) * C);
-      if (l == 0 && x == nullptr && tid < 192) {  // (slots[2] was written before the barrier above)
-        // the next board's packed input, by LDS-DMA into the buffer the running board does not use (waves 0 and 1: the 128
-        // ring words, lane 0 of wave 2: the player word); waited for at the top of the next board
+      constexpr int RWV = (RGW + 63) / 64;  // waves that carry ring words
+      if (l == 0 && x == nullptr && tid <= 64 * RWV) {  // (slots[2] was written before the barrier above)
+        // the next board's packed input, by LDS-DMA into the buffer the running board does not use (the first RWV waves: the
+        // RGW ring words, lane 0 of the wave after them: the player word); waited for at the top of the next board
         const int gn = __builtin_amdgcn_readfirstlane(slots[2]);
         if (gn >= 0) {
           uint32_t *dst = rgb + (rsel ^ 1) * RGS;
-          if (wave < 2)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ring + (size_t)gn * RGW + tid),
-                                             (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(dst + wave * 64), 4, 0, 0);
-          else if (tid == 128)
+          if (wave < RWV) {
+            if (tid < RGW)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ring + (size_t)gn * RGW + tid),
+                                               (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(dst + wave * 64), 4, 0, 0);
+          } else if (tid == 64 * RWV)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)&leafrec[gn].w,
                                              (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(dst + RGW), 4, 0, 0);
         }
@@ -789,7 +813,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       FSTAMP(8 + 4 * l);
       FSTAMP(9 + 4 * l);
       if (l + 2 < L) {
-        conv_layer16g<CW / 16, true, CW>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 2) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc,
+        conv_layer16g<CW / 16, true, CW, N>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, wl + (size_t)(l + 2) * 9 * (CW / 16) * KSB16, wave, lane, pp0, vm, acc, lc,
                                    wf);
         lfinal(bl + (2 + l) * C, true);
         FSTAMP(10 + 4 * l);
@@ -799,7 +823,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
         __syncthreads();
         FSTAMP(12 + 4 * l);
       } else {  // the tower's last layer: its output stays in the accumulators for the heads; prefetch the next board's stem
-        conv_layer16g<CW / 16, true, CW>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, w0, wave, lane, pp0, vm, acc, lc, wf);
+        conv_layer16g<CW / 16, true, CW, N>(act, wl + (size_t)(l + 1) * 9 * (CW / 16) * KSB16, w0, wave, lane, pp0, vm, acc, lc, wf);
         lfinal(bl + (2 + l) * C, true);
         FSTAMP(10 + 4 * l);
       }
@@ -807,17 +831,17 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
     // ---- heads: 1x1 convs + ReLU from the accumulators.  A lane holds 8 of its cell's channels (2 channel tiles x 4), the
     // four k-quarter groups of a wave hold the 32 channels of its half, the other half sits in wave ^ 2.
     {
-      const int ln = fresh(lane), kq = ln >> 4, pp0 = 7 * chalf * 16 + (ln & 15), lco = wave * 16 + (ln & 15);
-      float hs[7][3];
+      const int ln = fresh(lane), kq = ln >> 4, pp0 = NT * chalf * 16 + (ln & 15), lco = wave * 16 + (ln & 15);
+      float hs[NT][3];
 #pragma unroll
-      for (int pt = 0; pt < 7; ++pt) hs[pt][0] = hs[pt][1] = hs[pt][2] = 0.0f;
+      for (int pt = 0; pt < NT; ++pt) hs[pt][0] = hs[pt][1] = hs[pt][2] = 0.0f;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < NCT; ++ct) {
         f32x4 wv[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) wv[k] = *(const f32x4 *)(hw + k * C + ch * 32 + (ct ^ cto) * 16 + kq * 4);
+        for (int k = 0; k < 3; ++k) wv[k] = *(const f32x4 *)(hw + k * C + (ch * NCT + (ct ^ cto)) * 16 + kq * 4);
 #pragma unroll
-        for (int pt = 0; pt < 7; ++pt)
+        for (int pt = 0; pt < NT; ++pt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float a = fmaxf(acc[pt][ct][j], 0.0f);
@@ -827,7 +851,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
       }
       FSTAMP(26);
 #pragma unroll
-      for (int pt = 0; pt < 7; ++pt)
+      for (int pt = 0; pt < NT; ++pt)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {  // sum over the four k-quarter groups (same order on every lane of a cell)
           float t = hs[pt][k];
@@ -847,7 +871,7 @@ __global__ __launch_bounds__(CW * 4, 2) void k_tower_f32_t16(const float *__rest
         }
       }
 #pragma unroll
-      for (int pt = 0; pt < 7; ++pt) {
+      for (int pt = 0; pt < NT; ++pt) {
         if ((pt & 3) != kq) continue;  // the four k-quarter groups share the LDS stores (every lane holds the sum)
 #pragma unroll
         for (int k = 0; k < 3; ++k) hp[(ch * 3 + k) * NV + pp0 + 16 * pt] = hs[pt][k];
@@ -1038,7 +1062,7 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
         g_f32_attr_done[dev] |= 1u << variant;
       }
     }
-    static const int wg_per_cu = getenv("AZ_TOWER_F32_WG1") ? 1 : 2;  // diagnostic: one workgroup per CU
+    static const int wg_per_cu = getenv("AZ_TOWER_F32_WG1") ? 1 : 64;  // diagnostic: one workgroup per CU
     const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * (wg_per_cu < wg_cu ? wg_per_cu : wg_cu);  // workgroups that fit the chip
     const int grid = groups < cap ? groups : cap;
     const bool use_flags = !x_f32_dev && flags_dev;
@@ -1048,14 +1072,16 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
     return AZ_OK;
   };
   int rc;
-  auto lds_t16 = [](int cw) -> size_t {  // act + zero row, head filters, packed input, head partial sums, bias table
-    return (size_t)(226 * (4 * cw + 16)) + ((3 * cw + 3) * 4 + 15) / 16 * 16 + (2 * (128 + 4) + 8) * 4 + ((cw / 32) * 3 * 225 + 2 + 3 * (cw / 16)) * 4 +
+  auto lds_t16 = [](int cw, int n) -> size_t {  // act + zero row, head filters, packed input, head partial sums, bias table
+    const int nv = n * n, rgw = 16 * ((nv + 31) / 32), ncg = n == 15 ? cw / 32 : cw / 16, nw = n == 15 ? cw / 16 : cw / 16;
+    return (size_t)((nv + 1) * (4 * cw + 16)) + ((3 * cw + 3) * 4 + 15) / 16 * 16 + (2 * (rgw + 4) + 8) * 4 + (ncg * 3 * nv + 3 * nw + 3) / 4 * 16 +
            (size_t)(1 + T16_MAX_LAYERS) * cw * 4;
   };
   static const bool use32 = getenv("AZ_TOWER_F32_TILE32") != nullptr;  // diagnostic: the 32-cell-tile kernel on 15x15 too
-  if (channels == 128) rc = launch(k_tower_f32_t16<128>, lds_t16(128), 1, 3, 1, 512);
-  else if (board_size == 15 && !use32 && n_conv_layers <= T16_MAX_LAYERS) rc = launch(k_tower_f32_t16<64>, lds_t16(64), 1, 2);
+  if (channels == 128) rc = launch(k_tower_f32_t16<128, 15>, lds_t16(128, 15), 1, 3, 1, 512);
+  else if (board_size == 15 && !use32 && n_conv_layers <= T16_MAX_LAYERS) rc = launch(k_tower_f32_t16<64, 15>, lds_t16(64, 15), 1, 2);
   else if (board_size == 15) rc = launch(k_tower_f32<15, 1>, GeoF<15, 1>::lds_bytes(), 1, 0);
+  else if (!use32 && n_conv_layers <= T16_MAX_LAYERS) rc = launch(k_tower_f32_t16<64, 9>, lds_t16(64, 9), 1, 4, T16Geo<64, 9>::WG_PER_CU);
   else rc = launch(k_tower_f32<9, 3>, GeoF<9, 3>::lds_bytes(), 3, 1);
   if (rc != AZ_OK) return rc;
   const hipError_t err = hipGetLastError();

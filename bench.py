@@ -384,7 +384,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
                  + 32.0 * st["sum_depth"] + 36.0 * st["sims"]) / launches
     # the tree work of a simulation step is ONE launch: backup of simulation i + descent of simulation i+1
     dom = ("k_expand_select", sel_bytes + exp_bytes, tree_ms)
-    tower_kernel = "k_smallnet_f32" if game != 2 else ("k_tower_f32" if dtype_name == "f32" else "k_tower")
+    tower_kernel = "k_smallnet_f32" if game != 2 else ("k_tower_f32_t16" if dtype_name == "f32" else "k_tower")
 
     # HBM traffic from PMC counters cannot be collected inside this run (separate rocprofv3 --pmc passes,
     # scripts/pmc_traffic.sh); the last committed measurement of this same workload is reported, if present
@@ -420,7 +420,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
                    "flops_per_eval": flops_per_eval, "boards_per_batch": evals_per_launch,
                    "share_of_step": nn_ms / max(nn_ms + tree_ms, 1e-9),
                    "implementation": (("az_smallnet.hip: k_smallnet_f32 (the whole network, one f32 MFMA kernel)" if game != 2 else
-                                       "az_tower_f32.hip: k_tower_f32 (f32 MFMA conv tower) + k_heads_f32" if dtype_name == "f32" else
+                                       "az_tower_f32.hip: k_tower_f32_t16 (f32 MFMA conv tower, 16-cell tiles) + k_heads_f32" if dtype_name == "f32" else
                                        "az_tower.hip: k_tower (fused bf16 MFMA conv tower) + k_heads (MFMA head linears)")
                                       if evaluator == "fused" else "PyTorch/MIOpen module forward")}
         if evaluator == "fused" and tower_ms_raw is not None:

@@ -8,10 +8,11 @@ from alphazero_amd.nets import GomokuNet
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    B = 16384
-    net = GomokuNet(15, 64, 2).eval().cuda()
+    N = int(os.environ.get("BOARD", "15"))  # (TIME mode: BOARD=9 BATCH=4096 for BASELINE config 3's tower)
+    B = int(os.environ.get("BATCH", "16384"))
+    net = GomokuNet(N, 64, 2).eval().cuda()
     ev = FusedTowerEvaluator(net, "f32")
-    x = torch.randint(-1, 2, (B, 9, 15, 15), device="cuda").float()
+    x = torch.randint(-1, 2, (B, 9, N, N), device="cuda").float()
     ev(x)
     feat = ev._buf[B][0]
     lib = C.CDLL(os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "alphazero_amd/lib/dev/f32stamp.so"))
@@ -23,7 +24,7 @@ if __name__ == "__main__":
         for i in range(reps + 5):
             if i == 5:
                 e0.record()
-            lib.az_tower_forward_f32(15, 64, B, ev.n_layers, P(x), None, None, None, P(ev.w0), P(ev.wl), P(ev.bias), P(ev.headw), P(ev.headb),
+            lib.az_tower_forward_f32(N, 64, B, ev.n_layers, P(x), None, None, None, P(ev.w0), P(ev.wl), P(ev.bias), P(ev.headw), P(ev.headb),
                                      P(feat), ev.feat_stride, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         e1.record()
         torch.cuda.synchronize()

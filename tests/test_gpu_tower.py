@@ -52,7 +52,8 @@ def test_fused_tower_matches_fp32_forward(board, blocks, batch, ch):
 
 @pytest.mark.parametrize("board,blocks,batch,ch", [(15, 2, 64, 64), (15, 2, 1100, 64), (15, 3, 33, 64), (9, 2, 100, 64), (9, 1, 7, 64),
                                                    (15, 0, 5, 64), (9, 0, 4, 64), (15, 10, 600, 64), (9, 6, 50, 64),
-                                                   (15, 2, 300, 128), (15, 10, 270, 128), (15, 0, 9, 128)])
+                                                   (15, 2, 300, 128), (15, 10, 270, 128), (15, 0, 9, 128),
+                                                   (9, 2, 4096, 64), (9, 21, 40, 64), (15, 21, 5, 64)])  # (42 conv layers: the 32-cell-tile kernel)
 def test_f32_tower_matches_fp32_forward(board, blocks, batch, ch):
     """az_tower_f32.hip: f32 operands, f32 accumulation -- the reference's own arithmetic (nn_models/base.py:17-19).  Bar
     (north_star: priors within 1e-5 relative): logits within 2e-5 of the logit scale of PyTorch's f32 forward (which differs
@@ -231,9 +232,9 @@ def test_zero_block_tower_packed_flags_many_tickets(precision, board, G):
     eng.check()
 
 
-@pytest.mark.parametrize("ch,blocks", [(64, 2), (64, 0), (128, 1)])
-def test_f32_tower_lookahead_under_random_flags(ch, blocks):
-    """The 15x15 f32 tower hands boards out by ticket and looks the next board up under the running one (ticket, flag byte and
+@pytest.mark.parametrize("n,ch,blocks,G", [(15, 64, 2, 2100), (15, 64, 0, 2100), (15, 128, 1, 2100), (9, 64, 2, 5300), (9, 64, 0, 5300)])
+def test_f32_tower_lookahead_under_random_flags(n, ch, blocks, G):
+    """The f32 tower (16-cell-tile kernel, 15x15 and 9x9) hands boards out by ticket and looks the next board up under the running one (ticket, flag byte and
     packed input by LDS-DMA into a second buffer).  Synthetic packed batches with every kind of flag pattern -- dense, sparse,
     long runs of terminal leaves, only the last slot on, nothing on -- must give, on the flagged rows, exactly the features
     of the dense route, and leave the other rows alone."""
@@ -241,18 +242,18 @@ def test_f32_tower_lookahead_under_random_flags(ch, blocks):
     from alphazero_amd.nets import GomokuNet
 
     torch.manual_seed(11)
-    G, n = 2100, 15
     net = _randomised(GomokuNet(n, ch, blocks)).eval().cuda()
     ev = FusedTowerEvaluator(net, "f32")
     gen = torch.Generator().manual_seed(5)
     stones = torch.randint(-1, 2, (G, 8, n * n), generator=gen)          # 8 history states per slot
     player = torch.randint(0, 2, (G,), generator=gen) * 2 - 1
-    # packed form: per state 8 words of player-1 bits then 8 words of player-2 bits; leaf record .w = player to move
-    bits = torch.zeros(G, 8, 2, 256, dtype=torch.int64)
-    bits[:, :, 0, :225] = (stones == 1).long()
-    bits[:, :, 1, :225] = (stones == -1).long()
-    w = (bits.view(G, 8, 2, 8, 32) << torch.arange(32)).sum(-1)        # (G, 8, 2, 8) 32-bit words
-    ring = w.view(G, 128).to(torch.int64).cuda()
+    # packed form: per state WC = ceil(n*n / 32) words of player-1 bits then WC words of player-2 bits; leaf record .w = player to move
+    wc = (n * n + 31) // 32
+    bits = torch.zeros(G, 8, 2, 32 * wc, dtype=torch.int64)
+    bits[:, :, 0, :n * n] = (stones == 1).long()
+    bits[:, :, 1, :n * n] = (stones == -1).long()
+    w = (bits.view(G, 8, 2, wc, 32) << torch.arange(32)).sum(-1)       # (G, 8, 2, WC) 32-bit words
+    ring = w.view(G, 16 * wc).to(torch.int64).cuda()
     ring = (ring & 0xFFFFFFFF).to(torch.int64)
     ring32 = torch.where(ring >= 2 ** 31, ring - 2 ** 32, ring).to(torch.int32).contiguous()
     leaf = torch.zeros(G, 4, dtype=torch.int32)
