@@ -67,6 +67,13 @@ struct GeoF {
 
 __device__ __forceinline__ int act_addr(int p, int chunk) { return p * ROW + ((chunk ^ (p & 15)) << 4); }
 
+// Where input channel c (0..8) of the stem sits among the 16 padded channel positions, in the activations and in w0 alike:
+// positions 4 q + t with t < 3 only (0,1,2, 4,5,6, 8,9,10), so that element 3 of every 16-byte chunk is zero and the 16-cell-tile
+// kernel's stem issues three MFMAs per fragment instead of four (a quarter of the stem's MFMA time, 1.5 % of a two-block tower;
+// the dropped terms are exact zeros; the placement only fixes the ORDER in which the nine channels of a tap are summed, the
+// same in both kernels of this file).
+__host__ __device__ constexpr int stem_pos(int c) { return c + c / 3; }
+
 // async global -> LDS copy of 16 B per lane: the LDS destination is the wave-uniform `lds_base` + lane * 16
 __device__ __forceinline__ void glds16(const char *g_lane, char *lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
@@ -263,14 +270,14 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32(const float *__restrict__ 
         if (x != nullptr) {
           const float *xr = x + (size_t)g * 9 * NV + cell;
 #pragma unroll
-          for (int ch = 0; ch < 9; ++ch) c[ch] = xr[ch * NV];
+          for (int ch = 0; ch < 9; ++ch) c[stem_pos(ch)] = xr[ch * NV];
         } else {
           const uint32_t *rb = rg + b * 8 * SWB;
           const int wi = cell >> 5, sh = cell & 31;
 #pragma unroll
           for (int k = 0; k < 8; ++k)
-            c[k] = (float)(int)((rb[k * SWB + wi] >> sh) & 1u) - (float)(int)((rb[k * SWB + WC + wi] >> sh) & 1u);
-          c[8] = (int)rg[RGW + b] > 0 ? 1.0f : -1.0f;
+            c[stem_pos(k)] = (float)(int)((rb[k * SWB + wi] >> sh) & 1u) - (float)(int)((rb[k * SWB + WC + wi] >> sh) & 1u);
+          c[stem_pos(8)] = (int)rg[RGW + b] > 0 ? 1.0f : -1.0f;
         }
       }
 #pragma unroll
@@ -508,6 +515,7 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
   auto step = [&](int tap, auto mc, auto sc) {
     constexpr int M = decltype(mc)::value, S = decltype(sc)::value, V = (S + 3) % 4;
     constexpr bool TAP_END = M == KS16 - 1;
+    constexpr int NTT = KS16 == 1 ? 3 : 4;  // the stem's fourth element is a zero channel (stem_pos): no MFMA for it
     const bool last = TAP_END && tap == 8;
     {
       const int kn = tap * KS16 + M + 3;
@@ -519,13 +527,13 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
     __builtin_amdgcn_sched_barrier(0);
     if (LEFT) {  // cell 224, output channel 16 wave + r: that row of the weights IS this lane's a0 (see WFrag)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) lc = fmaf(wf[S].a0[t], lx[t], lc);
+      for (int t = 0; t < NTT; ++t) lc = fmaf(wf[S].a0[t], lx[t], lc);
       // (pins the sum HERE: left alone, the optimiser sinks the four k-steps' fmafs of a tap to the end of the loop body, which keeps
       // every weight set alive across the requests that refill it -- copies, and a wait for all of them, at the end of each tap)
       asm volatile("" : "+v"(lc));
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NTT; ++t)
 #pragma unroll
       for (int pt = 0; pt < NA; ++pt) {
         acc[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a0[t], fbA[pt][t], acc[pt][0], 0, 0, 0);
@@ -549,7 +557,7 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
       if (!last) set_tap_B();
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NTT; ++t)
 #pragma unroll
       for (int pt = 0; pt < NB; ++pt) {
         acc[NA + pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[S].a0[t], fbB[pt][t], acc[NA + pt][0], 0, 0, 0);
@@ -678,13 +686,13 @@ __global__ __launch_bounds__((64 * T16Geo<CW, N>::NW), (T16Geo<CW, N>::WG_PER_CU
       if (x != nullptr) {
         const float *xr = x + (size_t)g * 9 * NV + cell;
 #pragma unroll
-        for (int cc = 0; cc < 9; ++cc) c[cc] = xr[cc * NV];
+        for (int cc = 0; cc < 9; ++cc) c[stem_pos(cc)] = xr[cc * NV];
       } else {
         const int wi = cell >> 5, sh = cell & 31;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          c[k] = (float)(int)((rg[k * SWB + wi] >> sh) & 1u) - (float)(int)((rg[k * SWB + WC + wi] >> sh) & 1u);
-        c[8] = (int)rg[RGW] > 0 ? 1.0f : -1.0f;
+          c[stem_pos(k)] = (float)(int)((rg[k * SWB + wi] >> sh) & 1u) - (float)(int)((rg[k * SWB + WC + wi] >> sh) & 1u);
+        c[stem_pos(8)] = (int)rg[RGW] > 0 ? 1.0f : -1.0f;
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) *(f32x4 *)(act + act_addr(cell, k)) = (f32x4){c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]};

@@ -43,10 +43,13 @@ def _pack_linear(w: torch.Tensor, n_pad: int, k_pad: int, k_off_src: int = 0) ->
 
 
 def _pack3x3_f32(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
-    """(co, ci, 3, 3) f32 -> [tap 9][k-step ci/8][half 2][co][4] f32 (csrc/az_tower_f32.hip)"""
+    """(co, ci, 3, 3) f32 -> [tap 9][k-step ci/8][half 2][co][4] f32 (csrc/az_tower_f32.hip).  The stem (ci = 9 < cin_pad = 16)
+    puts input channel c at position c + c // 3 (csrc/az_tower_f32.hip: stem_pos): every fourth position stays zero"""
     co, ci = w.shape[0], w.shape[1]
     if ci < cin_pad:
-        w = torch.cat([w, w.new_zeros(co, cin_pad - ci, 3, 3)], 1)
+        wp = w.new_zeros(co, cin_pad, 3, 3)
+        wp[:, [c + c // 3 for c in range(ci)]] = w
+        w = wp
     t = w.permute(2, 3, 1, 0).reshape(9, cin_pad // 8, 2, 4, co)  # tap, ks, half, j, co
     return t.permute(0, 1, 2, 4, 3).contiguous().float()
 

@@ -259,10 +259,11 @@ int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16
 const char *az_tower_last_error(void);
 
 /* The same two calls at the REFERENCE'S precision: the reference runs its network in float32 (nn_models/base.py:17-19
- * under core/MCTS_alphazero.py:161-162, no autocast).  f32 operands and f32 accumulation on v_mfma_f32_32x32x2_f32
- * (each output is a k-ordered fmaf chain; dense peak 157.3 TFLOP/s).  64-channel trunks, board 9 or 15.
+ * under core/MCTS_alphazero.py:161-162, no autocast).  f32 operands and f32 accumulation on the f32 MFMAs (each output
+ * is a k-ordered fmaf chain; dense peak 157.3 TFLOP/s).  64-channel trunks on board 9 or 15, 128-channel trunks on board 15.
  *   x_f32_dev (n_boards, 9, N, N) f32 or NULL to read the packed leaf batch (with flags_dev, only the flagged slots);
- *   w0_dev [9 taps][2][2][64][4] f32, wl_dev [n_conv_layers][9][8][2][64][4] f32 ([tap][k-step of 8 ci][k-half][co][4 ci]);
+ *   w0_dev [9 taps][2][2][C][4] f32, wl_dev [n_conv_layers][9][C/8][2][C][4] f32 ([tap][k-step of 8 ci][k-half][co][4 ci]);
+ *   in w0 the 9 input channels sit at positions c + c / 3 of the 16 (0,1,2, 4,5,6, 8,9,10), the other positions are zero;
  *   bias_dev / headw_dev / headb_dev as for az_tower_forward; feat_f32_dev (n_boards, feat_stride) f32 out, same row
  *   layout and stride rule as az_tower_forward's (zeroed buffer: the pads are never written);
  *   az_heads_forward_f32: wp_dev [ceil(N*N/32)][KP/8][2][32][4] f32, w1_dev [2][KV/8][2][32][4] f32. */
