@@ -393,7 +393,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
         if args.workload != "gomoku15" or evaluator != "fused" or not os.path.exists(tpath):
             return None, None
         try:
-            t = json.load(open(tpath))[kernel]
+            d = json.load(open(tpath))
+            t = d[kernel] if kernel in d else d[kernel.replace("_t16", "")]
             return (t["FETCH_SIZE"]["corrected_bytes_per_launch"] + t["WRITE_SIZE"]["corrected_bytes_per_launch"],
                     "bytes per launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from separate --pmc passes "
                     "(scripts/pmc_traffic.sh -> profiles/pmc_traffic_latest.json)")

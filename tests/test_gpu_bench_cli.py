@@ -31,7 +31,7 @@ def test_bench_line_gomoku_f32_primary_with_bf16_beside_it_under_rccl():
     assert d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["kernel"] == "k_tower_f32" and r["peak"] == 157.3 and 0 < r["frac"] < 1
+    assert r["bound"] == "mfma" and r["kernel"] == "k_tower_f32_t16" and r["peak"] == 157.3 and 0 < r["frac"] < 1
     assert d["roofline_tree"]["bound"] == "hbm" and d["roofline_tree"]["peak"] == 8000.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
