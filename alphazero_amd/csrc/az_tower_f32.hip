@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_tower_f32(const float *__restrict__ 
                                                       const char *__restrict__ w0, const char *__restrict__ wl,
                                                       const float *__restrict__ bias, int L, const float *__restrict__ headw,
                                                       const float *__restrict__ headb, float *__restrict__ feat, int FS,
-                                                      unsigned int *tickets) {
+                                                      unsigned int *tickets, int /*BL: k_tower_f32_t16<.., true> only*/, float * /*stash*/) {
   using Q = GeoF<N, BPW>;
   constexpr int NV = Q::NV, NVT = Q::NVT, WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -582,13 +582,22 @@ __device__ __forceinline__ void conv_layer16g(const char *act, const char *wg, c
   }
 }
 
-template <int CW, int N>
+// QK = true: the same kernel for the reference's QuickModel family (nn_models/quick_model.py:67-93, resnet_blocks.py:28-40):
+// residual blocks of BL x (conv3x3 + BN + ReLU) whose sum x + block(x) is taken AFTER the last ReLU and is not activated again,
+// and 3x3 head convs (2 policy channels, 1 value channel).  A block's input has to outlive BL in-place layers: the lane that
+// overwrites an activation in the block's first epilogue sends the old value to `stash` (global memory, one private region per
+// workgroup, each wave-level store 1 KiB contiguous; the same lane reads it back in the block's last epilogue: 0.9 MB per board
+// of a 4 x 5-layer tower at 128 channels, L2 / Infinity Cache traffic) -- 56 more live registers per lane do not fit, a second
+// activation buffer does not fit the LDS at 128 channels.  The head convs need every cell's neighbours, so the last layer is
+// written to LDS like any other and the three head channels are summed on the VALU (0.06 % of the tower's flops) with the
+// filters [3][9 taps][CW] read through the scalar cache (headw; wave-uniform addresses).
+template <int CW, int N, bool QK = false>
 __global__ __launch_bounds__((64 * T16Geo<CW, N>::NW), (T16Geo<CW, N>::WG_PER_CU == 1 ? 2 : T16Geo<CW, N>::WG_PER_CU)) void k_tower_f32_t16(const float *__restrict__ x, const uint32_t *__restrict__ ring,
                                                           const int4 *__restrict__ leafrec, const uint8_t *__restrict__ flags, int G,
                                                           const char *__restrict__ w0, const char *__restrict__ wl,
                                                           const float *__restrict__ bias, int L, const float *__restrict__ headw,
                                                           const float *__restrict__ headb, float *__restrict__ feat, int FS,
-                                                          unsigned int *tickets) {
+                                                          unsigned int *tickets, int BL, float *__restrict__ stash) {
   using Q = T16Geo<CW, N>;
   constexpr int NV = Q::NV, WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, LCELL = Q::LCELL, KP = Q::KP, NT = Q::NT, NCT = Q::NCT;
   constexpr int C = CW, ROW = T16_ROW<CW>, NW = Q::NW, NTH = 64 * NW, NCQ = Q::NCG;  // padded row bytes; waves; channel groups
@@ -787,6 +796,131 @@ __global__ __launch_bounds__((64 * T16Geo<CW, N>::NW), (T16Geo<CW, N>::WG_PER_CU
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(flags + tk),
                                          (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(slots + 4), 1, 0, 0);
     }
+    if constexpr (QK) {
+      // ---- QuickModel blocks: every layer conv + bias + ReLU in place; first layer of a block stashes its input, last adds it back
+      constexpr int STW = NT * NCT * 256 + 64;  // floats per wave in the stash: NT x NCT fragments of 64 lanes x 4, the corner cell's 16
+      float *const st = stash + ((size_t)blockIdx.x * NW + wave) * STW;
+      auto epilogue_q = [&](bool first, bool lastl) {
+        const int ln = fresh(lane), kq = ln >> 4, pp0 = NT * chalf * 16 + (ln & 15);
+        float *const lptr = corner_ptr(ln);
+        float *const sl = st + ln * 4;
+        if (lastl && !first) {  // the block's last layer: relu(conv) + the stashed block input (all requests first, then the sums)
+          f32x4 xr[NT][NCT];
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < NT; ++pt) xr[pt][ct] = *(const f32x4 *)(sl + (pt * NCT + ct) * 256);
+          const float lr = kq == 0 ? st[NT * NCT * 256 + ln] : 0.0f;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < NT; ++pt) {
+              f32x4 v;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[pt][ct][j], 0.0f) + xr[pt][ct][j];
+              *(f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * NCT + (ct ^ cto)) * 4 + kq)) = v;
+            }
+          if (kq == 0) *lptr = fmaxf(lc, 0.0f) + lr;
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < NT; ++pt) {
+              f32x4 *const p = (f32x4 *)(act + act_addr((pp0 + 16 * pt), (ch * NCT + (ct ^ cto)) * 4 + kq));
+              f32x4 v;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[pt][ct][j], 0.0f);
+              if (first) {  // (this lane overwrites exactly the activations it stashes: no other lane needs them again)
+                const f32x4 xo = *p;
+                if (lastl) v = v + xo;  // a one-layer block
+                else *(f32x4 *)(sl + (pt * NCT + ct) * 256) = xo;
+              }
+              *p = v;
+            }
+          if (kq == 0) {
+            float v = fmaxf(lc, 0.0f);
+            if (first) {
+              const float xo = *lptr;
+              if (lastl) v = v + xo;
+              else st[NT * NCT * 256 + ln] = xo;
+            }
+            *lptr = v;
+          }
+        }
+      };
+      constexpr size_t LSTRIDE = (size_t)9 * (CW / 16) * KSB16;
+      int j = 0;  // layer of its block
+      for (int l = 0; l < L; ++l) {
+        init(bl + (1 + l) * C);
+        conv_layer16g<CW / 16, true, CW, N>(act, wl + (size_t)l * LSTRIDE, l + 1 < L ? wl + (size_t)(l + 1) * LSTRIDE : w0, wave, lane, pp0, vm, acc, lc, wf);
+        lfinal(bl + (1 + l) * C, false);
+        if (l == 0 && tid == 0) {  // publish the next board's slot
+          const int tk = slots[3];
+          slots[2] = tk >= G ? -1 : ((flags == nullptr || (slots[4] & 0xFF) != 0) ? tk : -2);
+        }
+        __syncthreads();  // every wave has read the layer's input
+        epilogue_q(j == 0, j == BL - 1);
+        constexpr int RWV = (RGW + 63) / 64;
+        if (l == 0 && x == nullptr && tid <= 64 * RWV) {  // the next board's packed input by LDS-DMA (as in the other branch)
+          const int gn = __builtin_amdgcn_readfirstlane(slots[2]);
+          if (gn >= 0) {
+            uint32_t *dst = rgb + (rsel ^ 1) * RGS;
+            if (wave < RWV) {
+              if (tid < RGW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ring + (size_t)gn * RGW + tid),
+                                                 (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(dst + wave * 64), 4, 0, 0);
+            } else if (tid == 64 * RWV)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)&leafrec[gn].w,
+                                               (__attribute__((address_space(3))) void *)(uint32_t)(uintptr_t)(dst + RGW), 4, 0, 0);
+          }
+        }
+        __syncthreads();
+        j = j + 1 == BL ? 0 : j + 1;
+      }
+      // ---- heads: the three 3x3 head convs (+ folded BN) on the VALU from the finished activations.  A thread takes one cell and
+      // CPS of its channels (splits are wave-uniform: the filters come through the scalar cache); partial sums per split in LDS
+      {
+        constexpr int CELLS_T = N == 9 ? 128 : 256, SPL = NTH / CELLS_T, CPS = CW / SPL, KPQ = (2 * NV + 15) / 16 * 16;
+        static_assert(SPL >= 1 && SPL <= NCQ && CELLS_T >= NV, "a thread per cell and split; hp holds SPL x 3 x NV sums");
+        const int cell = fresh(tid) & (CELLS_T - 1), split = wave / (CELLS_T / 64);
+        if (cell < NV) {
+          const int row = cell / N, col = cell - row * N;
+          const float *wq = headw + split * CPS;
+          float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll 1
+          for (int tap = 0; tap < 9; ++tap) {
+            const int dr = tap / 3 - 1, dc = tap - (tap / 3) * 3 - 1, rr = row + dr, cc = col + dc;
+            const bool on = rr >= 0 && rr < N && cc >= 0 && cc < N;
+            const char *ap = act + (on ? cell + dr * N + dc : NV) * ROW + split * (CPS * 4);
+            const float *wt = wq + tap * CW;
+#pragma unroll
+            for (int c4 = 0; c4 < CPS / 4; ++c4) {
+              const f32x4 a = *(const f32x4 *)(ap + c4 * 16);
+              const f32x4 u0 = *(const f32x4 *)(wt + c4 * 4), u1 = *(const f32x4 *)(wt + 9 * CW + c4 * 4), u2 = *(const f32x4 *)(wt + 18 * CW + c4 * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                s0 = fmaf(a[e], u0[e], s0);
+                s1 = fmaf(a[e], u1[e], s1);
+                s2 = fmaf(a[e], u2[e], s2);
+              }
+            }
+          }
+          hp[(split * 3 + 0) * NV + cell] = s0;
+          hp[(split * 3 + 1) * NV + cell] = s1;
+          hp[(split * 3 + 2) * NV + cell] = s2;
+        }
+        __syncthreads();
+        // feature rows [policy0 NV | policy1 NV | pad to 16 | value NV | pad to 16] (Flatten of (2, N, N) and of (1, N, N))
+        float *fr = feat + (size_t)g * FS;
+        for (int e = tid; e < 3 * NV; e += NTH) {
+          const int k = e / NV, cell2 = e - k * NV;
+          float v = 0.0f;
+#pragma unroll
+          for (int c = 0; c < SPL; ++c) v += hp[(3 * c + k) * NV + cell2];
+          fr[(k < 2 ? k * NV : KPQ) + cell2] = fmaxf(v + hw[3 * C + k], 0.0f);
+        }
+      }
+    } else {
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
       init(bl + (1 + l) * C);
@@ -903,6 +1037,7 @@ __global__ __launch_bounds__((64 * T16Geo<CW, N>::NW), (T16Geo<CW, N>::WG_PER_CU
         fr[(k == 0 ? 0 : KP + (k - 1) * NV) + cell] = fmaxf(v + hw[3 * C + k], 0.0f);
       }
     }
+    }  // !QK
     FSTAMP(30);
   }
 #if AZ_F32_STAMP
@@ -996,6 +1131,76 @@ __global__ __launch_bounds__(256, 2) void k_heads_f32(const float *__restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The QuickModel heads' Linear layers in f32 (nn_models/quick_model.py:138-154, 185-199 with config/quick_model_config.py's
+// defaults: two Linear layers per head, 64 hidden features):
+//   logits = relu(feat[:, :2NV] @ W1p^T + b1p) @ W2p^T + b2p;   value = tanh(relu(feat[:, KPQ:KPQ+NV] @ W1v^T + b1v) @ w2v + b2v)
+// One workgroup = 32 boards.  Phase 1: wave w = hidden tile (w & 1) of head (w >> 1) as an f32 MFMA GEMM (A = feature rows,
+// B = weights packed [n-tile][k-step of 8][half][n 32][4 k], zero padded), bias + ReLU into LDS.  Phase 2: the policy's second
+// layer as MFMA GEMMs from LDS (output tiles wave, wave + 4, ...); the value's second layer as a k-ordered fmaf chain per board.
+template <int NV>
+__global__ __launch_bounds__(256, 2) void k_quick_heads_f32(const float *__restrict__ feat, int FS, int G, const char *__restrict__ w1p,
+                                                            const float *__restrict__ b1p, const char *__restrict__ w2p,
+                                                            const float *__restrict__ b2p, const char *__restrict__ w1v,
+                                                            const float *__restrict__ b1v, const float *__restrict__ w2v, float b2v,
+                                                            float *__restrict__ logits, float *__restrict__ values) {
+  constexpr int KPQ = (2 * NV + 15) / 16 * 16, KVQ = (NV + 15) / 16 * 16, NTP = (NV + 31) / 32, HS = 68;
+  __shared__ __attribute__((aligned(16))) float hid[2][32][HS];  // [head][board][hidden unit], rows padded to 68 floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int g0 = blockIdx.x * 32;
+  const float *fa = feat + (size_t)min(g0 + r, G - 1) * FS + 4 * h;  // rows past the batch: a copy of the last row, not stored
+  {
+    const int head = wave >> 1, nt = wave & 1;
+    const int ksn = head == 0 ? KPQ / 8 : KVQ / 8;
+    const char *wb = (head == 0 ? w1p : w1v) + ((size_t)nt * ksn * 2 + h) * 512 + r * 16;
+    const float *fh = fa + (head == 0 ? 0 : KPQ);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll 6
+    for (int ks = 0; ks < ksn; ++ks) {
+      const f32x4 b = *(const f32x4 *)(wb + (size_t)ks * 1024);
+      const f32x4 a = *(const f32x4 *)(fh + ks * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+    const int n = nt * 32 + r;
+    const float bn = (head == 0 ? b1p : b1v)[n];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hid[head][(i & 3) + 8 * (i >> 2) + 4 * h][n] = fmaxf(acc[i] + bn, 0.0f);
+  }
+  __syncthreads();
+  for (int nt = wave; nt < NTP; nt += 4) {
+    const char *wb = w2p + ((size_t)nt * 8 * 2 + h) * 512 + r * 16;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const f32x4 b = *(const f32x4 *)(wb + (size_t)ks * 1024);
+      const f32x4 a = *(const f32x4 *)(&hid[0][r][ks * 8 + 4 * h]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+    const int n = nt * 32 + r;
+    if (n < NV) {
+      const float bias = b2p[n];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (g0 + row < G) logits[(size_t)(g0 + row) * NV + n] = acc[i] + bias;
+      }
+    }
+  }
+  if (tid < 32 && g0 + tid < G) {
+    float t = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) t = fmaf(hid[1][tid][k], w2v[k], t);
+    values[g0 + tid] = tanhf(t + b2v);
+  }
+}
+
 }  // namespace aztf32
 
 static std::mutex g_f32_mutex;
@@ -1076,7 +1281,7 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
     const bool use_flags = !x_f32_dev && flags_dev;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, x_f32_dev, (const uint32_t *)packed_ring_dev, (const int4 *)packed_leaf_dev,
                        (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
-                       n_conv_layers, headw_dev, headb_dev, feat_f32_dev, (int)feat_stride, tickets);
+                       n_conv_layers, headw_dev, headb_dev, feat_f32_dev, (int)feat_stride, tickets, 2, (float *)nullptr);
     return AZ_OK;
   };
   int rc;
@@ -1094,6 +1299,99 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
   if (rc != AZ_OK) return rc;
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) { tower_set_error(std::string("k_tower_f32 launch: ") + hipGetErrorString(err)); return AZ_EHIP; }
+  return AZ_OK;
+}
+
+int64_t az_quick_stash_bytes(int32_t board_size, int32_t channels) {
+  using namespace aztf32;
+  if (board_size == 15 && channels == 128) return (int64_t)256 * 1 * T16Geo<128, 15>::NW * (T16Geo<128, 15>::NT * T16Geo<128, 15>::NCT * 256 + 64) * 4;
+  if (board_size == 15 && channels == 64) return (int64_t)256 * 2 * T16Geo<64, 15>::NW * (T16Geo<64, 15>::NT * T16Geo<64, 15>::NCT * 256 + 64) * 4;
+  if (board_size == 9 && channels == 64) return (int64_t)256 * T16Geo<64, 9>::WG_PER_CU * T16Geo<64, 9>::NW * (T16Geo<64, 9>::NT * T16Geo<64, 9>::NCT * 256 + 64) * 4;
+  return -1;
+}
+
+int az_quick_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_blocks, int32_t block_layers,
+                               const float *x_f32_dev, const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev,
+                               const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
+                               const float *headb_dev, float *feat_f32_dev, int32_t feat_stride, void *stash_dev, int64_t stash_bytes,
+                               void *stream) {
+  using namespace aztf32;
+  if ((!x_f32_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !wl_dev || !bias_dev || !headw_dev || !headb_dev || !feat_f32_dev ||
+      !stash_dev) { tower_set_error("null argument"); return AZ_EINVAL; }
+  if (n_boards < 1 || n_blocks < 1 || block_layers < 1 || (int64_t)n_blocks * block_layers > T16_MAX_LAYERS) {
+    tower_set_error("quick tower: n_boards >= 1, n_blocks >= 1, block_layers >= 1, at most 40 conv layers after the transition conv");
+    return AZ_EINVAL;
+  }
+  const int64_t need = az_quick_stash_bytes(board_size, channels);
+  if (need < 0) { tower_set_error("quick tower: board_size 9 or 15 with 64 channels, or 15 with 128 channels"); return AZ_EINVAL; }
+  if (stash_bytes < need) { tower_set_error("quick tower: stash_bytes below az_quick_stash_bytes(board_size, channels)"); return AZ_EINVAL; }
+  if (feat_stride < az_heads_feat_stride(board_size)) { tower_set_error("feat_stride below az_heads_feat_stride(board_size)"); return AZ_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  int dev = 0, cur = 0;
+  if (tower_device(s, &dev) != 0 || dev < 0 || dev >= 64) { tower_set_error("cannot tell the stream's device"); return AZ_EHIP; }
+  if (hipGetDevice(&cur) != hipSuccess) { tower_set_error("hipGetDevice failed"); return AZ_EHIP; }
+  struct DeviceGuard {
+    int back;
+    DeviceGuard(int want, int cur_) : back(want != cur_ ? cur_ : -1) { if (back >= 0) (void)hipSetDevice(want); }
+    ~DeviceGuard() { if (back >= 0) (void)hipSetDevice(back); }
+  } guard(dev, cur);
+  unsigned int *tickets = tower_tickets(dev, s);
+  if (tickets == nullptr) return AZ_EHIP;
+  const int L = n_blocks * block_layers;
+  auto lds_t16 = [](int cw, int n) -> size_t {  // as in az_tower_forward_f32
+    const int nv = n * n, rgw = 16 * ((nv + 31) / 32), ncg = n == 15 ? cw / 32 : cw / 16, nw = cw / 16;
+    return (size_t)((nv + 1) * (4 * cw + 16)) + ((3 * cw + 3) * 4 + 15) / 16 * 16 + (2 * (rgw + 4) + 8) * 4 + (ncg * 3 * nv + 3 * nw + 3) / 4 * 16 +
+           (size_t)(1 + T16_MAX_LAYERS) * cw * 4;
+  };
+  auto launch = [&](auto kern, size_t lds, int variant, int wg_cu, int threads) -> int {
+    if (lds * wg_cu > 160 * 1024) { tower_set_error("quick tower geometry exceeds the CU's LDS"); return AZ_EINVAL; }
+    {
+      std::lock_guard<std::mutex> lock(g_f32_mutex);
+      if (!(g_f32_attr_done[dev] & (1u << variant))) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          tower_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+          return AZ_EHIP;
+        }
+        g_f32_attr_done[dev] |= 1u << variant;
+      }
+    }
+    const int cap = 256 * wg_cu, grid = n_boards < cap ? n_boards : cap;  // (the stash holds one region per workgroup of a full grid)
+    const bool use_flags = !x_f32_dev && flags_dev;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, x_f32_dev, (const uint32_t *)packed_ring_dev, (const int4 *)packed_leaf_dev,
+                       (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev, L,
+                       headw_dev, headb_dev, feat_f32_dev, (int)feat_stride, tickets, (int)block_layers, (float *)stash_dev);
+    return AZ_OK;
+  };
+  int rc;
+  if (channels == 128) rc = launch(k_tower_f32_t16<128, 15, true>, lds_t16(128, 15), 8, 1, 512);
+  else if (board_size == 15) rc = launch(k_tower_f32_t16<64, 15, true>, lds_t16(64, 15), 9, 2, 256);
+  else rc = launch(k_tower_f32_t16<64, 9, true>, lds_t16(64, 9), 10, T16Geo<64, 9>::WG_PER_CU, 256);
+  if (rc != AZ_OK) return rc;
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) { tower_set_error(std::string("k_tower_f32_t16 (quick) launch: ") + hipGetErrorString(err)); return AZ_EHIP; }
+  return AZ_OK;
+}
+
+int az_quick_heads_forward_f32(int32_t board_size, int32_t n_boards, const float *feat_dev, int32_t feat_stride, const void *w1p_dev,
+                               const float *b1p_dev, const void *w2p_dev, const float *b2p_dev, const void *w1v_dev,
+                               const float *b1v_dev, const float *w2v_dev, float b2v, float *logits_dev, float *values_dev, void *stream) {
+  using namespace aztf32;
+  if (!feat_dev || !w1p_dev || !b1p_dev || !w2p_dev || !b2p_dev || !w1v_dev || !b1v_dev || !w2v_dev || !logits_dev || !values_dev) {
+    tower_set_error("null argument");
+    return AZ_EINVAL;
+  }
+  if (n_boards < 1 || (board_size != 9 && board_size != 15)) { tower_set_error("n_boards >= 1, board_size 9 or 15"); return AZ_EINVAL; }
+  if (feat_stride < az_heads_feat_stride(board_size) || (feat_stride & 3)) { tower_set_error("feat_stride: a multiple of 4, at least az_heads_feat_stride(board_size)"); return AZ_EINVAL; }
+  const dim3 grid((n_boards + 31) / 32), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (board_size == 15)
+    hipLaunchKernelGGL((k_quick_heads_f32<225>), grid, block, 0, s, feat_dev, (int)feat_stride, (int)n_boards, (const char *)w1p_dev, b1p_dev,
+                       (const char *)w2p_dev, b2p_dev, (const char *)w1v_dev, b1v_dev, w2v_dev, b2v, logits_dev, values_dev);
+  else
+    hipLaunchKernelGGL((k_quick_heads_f32<81>), grid, block, 0, s, feat_dev, (int)feat_stride, (int)n_boards, (const char *)w1p_dev, b1p_dev,
+                       (const char *)w2p_dev, b2p_dev, (const char *)w1v_dev, b1v_dev, w2v_dev, b2v, logits_dev, values_dev);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) { tower_set_error(std::string("k_quick_heads_f32 launch: ") + hipGetErrorString(err)); return AZ_EHIP; }
   return AZ_OK;
 }
 

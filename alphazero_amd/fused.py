@@ -4,7 +4,12 @@ runs as ONE hand-written bf16 MFMA kernel
 (csrc/az_tower.hip, activations resident in LDS); eval-mode BatchNorm is folded into the conv weights
 here; the heads' Linear layers run as one more small MFMA kernel (az_heads_forward).  Same contract as the module it wraps:
 ``(B, 9, N, N) -> (logits (B, N*N) f32, value (B, 1) f32)``.  Call ``refresh()`` after the module's
-weights change (load_state_dict / weight publish)."""
+weights change (load_state_dict / weight publish).
+
+The reference's QuickModel family (nn_models/quick_model.py with config/quick_model_config.py's default layout, any depth:
+alphazero_amd.nets.QuickNet) is evaluated by the float32 tower only (precision="f32": az_quick_tower_forward_f32 +
+az_quick_heads_forward_f32) -- blocks of ``layers`` x (conv3x3, BN, ReLU) summed with their input after the last ReLU,
+3x3 head convs, two Linear layers per head."""
 from __future__ import annotations
 
 import ctypes as C
@@ -65,7 +70,47 @@ def _pack_linear_f32(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
 
 class FusedTowerEvaluator:
     @staticmethod
+    def quick_shape(model: nn.Module):
+        """(board, channels, blocks, layers per block) when the module is a QuickModel-family network the f32 tower evaluates
+        (nets.QuickNet / nn_models/quick_model.py defaults: BatchNorm on, one transition conv, 3x3 head convs with 2 / 1
+        channels, two Linear layers of 64 features per head, N*N actions), else None"""
+        try:
+            sl, ph, vh = list(model._shared_layers), list(model._policy_head), list(model._value_head)
+            stem, blocks = sl[0], sl[3:]
+            ch = stem.out_channels
+            conv3 = lambda c, i, o: isinstance(c, nn.Conv2d) and (c.in_channels, c.out_channels) == (i, o) and \
+                c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride == (1, 1)
+            if not (conv3(stem, 9, ch) and isinstance(sl[1], nn.BatchNorm2d) and isinstance(sl[2], nn.ReLU) and blocks):
+                return None
+            layers = None
+            for b in blocks:
+                seq = list(b.model)
+                if len(seq) % 3 or not seq or (layers is not None and len(seq) != 3 * layers):
+                    return None
+                layers = len(seq) // 3
+                for i in range(layers):
+                    if not (conv3(seq[3 * i], ch, ch) and isinstance(seq[3 * i + 1], nn.BatchNorm2d) and isinstance(seq[3 * i + 2], nn.ReLU)):
+                        return None
+            lin = lambda m, i, o: isinstance(m, nn.Linear) and (m.in_features, m.out_features) == (i, o) and m.bias is not None
+            if len(ph) != 7 or len(vh) != 7 or not isinstance(ph[6], nn.Linear):
+                return None
+            n2 = ph[6].out_features
+            board = {81: 9, 225: 15}.get(n2)
+            ok = board is not None and conv3(ph[0], ch, 2) and isinstance(ph[1], nn.BatchNorm2d) and isinstance(ph[2], nn.ReLU) and \
+                isinstance(ph[3], nn.Flatten) and lin(ph[4], 2 * n2, 64) and isinstance(ph[5], nn.ReLU) and lin(ph[6], 64, n2) and \
+                conv3(vh[0], ch, 1) and isinstance(vh[1], nn.BatchNorm2d) and isinstance(vh[2], nn.ReLU) and \
+                isinstance(vh[3], nn.Flatten) and lin(vh[4], n2, 64) and isinstance(vh[5], nn.ReLU) and lin(vh[6], 64, 1)
+            # (the family's tanh lives in the module's value_head method, nn_models/quick_model.py:102-104, not in the Sequential:
+            # the kernel applies it)
+            ok = ok and (ch == 64 or (ch == 128 and board == 15)) and len(blocks) * layers <= 40
+            return (board, ch, len(blocks), layers) if ok else None
+        except Exception:
+            return None
+
+    @staticmethod
     def supports(model: nn.Module) -> bool:
+        if FusedTowerEvaluator.quick_shape(model) is not None:
+            return True
         try:
             sl = model._shared_layers
             stem, blocks = sl[0], [m for m in list(sl)[3:]]
@@ -87,17 +132,28 @@ class FusedTowerEvaluator:
         (az_tower_f32.hip: f32 MFMA, the reference's own arithmetic, 64-channel trunks).  The weights are folded and
         packed from the module's parameters in f32 either way, whatever dtype the module itself holds."""
         if not self.supports(model):
-            raise EngineError("FusedTowerEvaluator: not a GomokuModel-family network (64- or 128-channel 3x3 residual tower)")
+            raise EngineError("FusedTowerEvaluator: not a GomokuModel- or QuickModel-family network (64- or 128-channel 3x3 residual tower)")
         self.lib = load_library()
         self.model = model
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
             raise EngineError("FusedTowerEvaluator needs the model on a GPU")
+        if precision not in ("bf16", "f32"):
+            raise EngineError("FusedTowerEvaluator: precision must be 'bf16' or 'f32'")
+        self.quick = self.quick_shape(model)
+        if self.quick is not None:
+            if precision != "f32":
+                raise EngineError("FusedTowerEvaluator: QuickModel-family networks run on the float32 tower (precision='f32')")
+            self.board, self.ch, self.q_blocks, self.q_layers = self.quick
+            self.n2 = self.board * self.board
+            self.precision, self.in_dtype = "f32", torch.float32
+            self._buf = {}
+            self.kernel_events = None
+            self.refresh()
+            return
         self.n2 = model._policy_head[4].in_features
         self.board = 15 if self.n2 == 225 else 9
         self.ch = model._shared_layers[0].out_channels
-        if precision not in ("bf16", "f32"):
-            raise EngineError("FusedTowerEvaluator: precision must be 'bf16' or 'f32'")
         if precision == "f32" and not (self.ch == 64 or (self.ch == 128 and self.board == 15)):
             raise EngineError("FusedTowerEvaluator: the f32 tower exists for 64-channel trunks (9x9, 15x15) and 128-channel 15x15 trunks")
         self.precision = precision
@@ -107,7 +163,49 @@ class FusedTowerEvaluator:
         self.refresh()
 
     @torch.no_grad()
+    def _refresh_quick(self) -> None:
+        m, dev, n2 = self.model, self.device, self.n2
+        sl = list(m._shared_layers)
+        w, b = _fold(sl[0], sl[1])
+        self.w0 = _pack3x3_f32(w, 16).to(dev)
+        biases, wl = [b], []
+        for blk in sl[3:]:
+            seq = list(blk.model)
+            for i in range(self.q_layers):
+                w, b = _fold(seq[3 * i], seq[3 * i + 1])
+                wl.append(_pack3x3_f32(w, self.ch))
+                biases.append(b)
+        self.n_layers = len(wl)
+        self.wl = torch.stack(wl).to(dev).contiguous()
+        self.bias = torch.stack(biases).to(dev).contiguous()
+        ph, vh = list(m._policy_head), list(m._value_head)
+        pw, pb = _fold(ph[0], ph[1])  # (2, ch, 3, 3)
+        vw, vb = _fold(vh[0], vh[1])  # (1, ch, 3, 3)
+        # [3 head channels][9 taps][ch] f32: policy0, policy1, value
+        self.headw = torch.cat([pw, vw]).permute(0, 2, 3, 1).reshape(3, 9, self.ch).to(dev).contiguous()
+        self.headb = torch.cat([pb, vb]).to(dev).contiguous()
+        f = lambda t: t.detach().float().to(dev).contiguous()
+        self.kpq, self.kvq = (2 * n2 + 15) // 16 * 16, (n2 + 15) // 16 * 16
+        self.feat_stride = int(self.lib.az_heads_feat_stride(self.board))
+        assert self.feat_stride == self.kpq + self.kvq
+        self.w1p = _pack_linear_f32(f(ph[4].weight), 64, self.kpq).to(dev)
+        self.b1p = f(ph[4].bias)
+        self.w2p = _pack_linear_f32(f(ph[6].weight), (n2 + 31) // 32 * 32, 64).to(dev)
+        self.b2p = f(ph[6].bias)
+        self.w1v = _pack_linear_f32(f(vh[4].weight), 64, self.kvq).to(dev)
+        self.b1v = f(vh[4].bias)
+        self.w2v = f(vh[6].weight).reshape(-1)
+        self.b2v = float(vh[6].bias.detach().float().reshape(-1)[0])
+        self.stash_bytes = int(self.lib.az_quick_stash_bytes(self.board, self.ch))
+        if self.stash_bytes <= 0:
+            raise EngineError("az_quick_stash_bytes: unsupported board / width")
+        if getattr(self, "stash", None) is None:  # block inputs in flight: one private region per workgroup of a full grid
+            self.stash = torch.empty(self.stash_bytes // 4, dtype=torch.float32, device=dev)
+
+    @torch.no_grad()
     def refresh(self) -> None:
+        if self.quick is not None:
+            return self._refresh_quick()
         m, dev = self.model, self.device
         sl = list(m._shared_layers)
         blocks = sl[3:]
@@ -178,6 +276,22 @@ class FusedTowerEvaluator:
         if self.kernel_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        if self.quick is not None:
+            if list_p is not None:
+                raise EngineError("the f32 tower takes the packed batch with flags (or all slots), not a compact list")
+            rc = self.lib.az_quick_tower_forward_f32(self.board, self.ch, B, self.q_blocks, self.q_layers, P(x) if x is not None else None,
+                                                     ring_p, leaf_p, flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.headw),
+                                                     P(self.headb), P(feat), self.feat_stride, P(self.stash), self.stash_bytes, st)
+            if rc != 0:
+                raise EngineError(f"az_quick_tower_forward_f32 failed ({rc}): {self.lib.az_tower_last_error().decode()}")
+            if self.kernel_events is not None:
+                ev1.record()
+                self.kernel_events.append((ev0, ev1))
+            rc = self.lib.az_quick_heads_forward_f32(self.board, B, P(feat), self.feat_stride, P(self.w1p), P(self.b1p), P(self.w2p),
+                                                     P(self.b2p), P(self.w1v), P(self.b1v), P(self.w2v), self.b2v, P(logits), P(value), st)
+            if rc != 0:
+                raise EngineError(f"az_quick_heads_forward_f32 failed ({rc}): {self.lib.az_tower_last_error().decode()}")
+            return logits, value.view(B, 1)
         if self.precision == "f32":
             if list_p is not None:
                 raise EngineError("the f32 tower takes the packed batch with flags (or all slots), not a compact list")

@@ -275,6 +275,33 @@ int az_heads_forward_f32(int32_t board_size, int32_t n_boards, const float *feat
                          const float *bp_dev, const void *w1_dev, const float *b1_dev, const float *w2_dev, float b2,
                          float *logits_dev, float *values_dev, void *stream);
 
+/* The reference's QuickModel family at the reference's precision (nn_models/quick_model.py:67-93 with the layout of
+ * config/quick_model_config.py's defaults -- BatchNorm on, one transition conv, 3x3 head convs of 2 / 1 channels, two Linear
+ * layers of 64 features per head -- at any depth; residual block nn_models/resnet_blocks.py:28-40: x + (conv3x3, BN, ReLU) x
+ * block_layers, the sum taken after the last ReLU and not activated again; tanh on the value, quick_model.py:102-104).  The same
+ * f32 MFMA tower kernel as az_tower_forward_f32 in its QuickModel instantiation, and the heads' Linear layers.
+ *   n_blocks x block_layers conv layers after the transition conv (at most 40); x / packed_* / flags / w0 / wl / bias as for
+ *   az_tower_forward_f32 (wl_dev [n_blocks * block_layers][9][C/8][2][C][4] f32, bias_dev [1 + n_blocks * block_layers][C]);
+ *   headw_dev [3][9 taps][C] f32 = the 3x3 head convs (policy channel 0, policy channel 1, value) with BN folded in, headb_dev [3];
+ *   feat_f32_dev (n_boards, feat_stride) f32 out, row layout [policy0 N*N | policy1 N*N | zero pad to a multiple of 16 |
+ *   value N*N | zero pad to a multiple of 16] = az_heads_feat_stride(N) floats (zeroed buffer: the pads are never written);
+ *   stash_dev: az_quick_stash_bytes(N, C) bytes of device memory the kernel keeps the running blocks' inputs in (a private
+ *   region per workgroup; contents meaningless between calls; calls that share one stash must not overlap in time).
+ * az_quick_heads_forward_f32:  logits = relu(feat[:, :2N*N] @ W1p^T + b1p) @ W2p^T + b2p;
+ *                              value = tanh(relu(feat[:, KPQ:KPQ+N*N] @ W1v^T + b1v) @ w2v + b2v),  KPQ = 2N*N rounded up to 16;
+ *   w1p_dev [2][KPQ/8][2][32][4], w2p_dev [ceil(N*N/32)][8][2][32][4], w1v_dev [2][KVQ/8][2][32][4] f32 ([output tile][k-step of
+ *   8][k-half][output][4 k], zero padded; KVQ = N*N rounded up to 16); b1p (64), b2p (N*N), b1v (64), w2v (64) f32, b2v.
+ * Boards 9 and 15 with 64 channels, board 15 with 128 channels.  Errors through az_tower_last_error(). */
+int64_t az_quick_stash_bytes(int32_t board_size, int32_t channels);
+int az_quick_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_blocks, int32_t block_layers,
+                               const float *x_f32_dev, const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev,
+                               const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev,
+                               const float *headb_dev, float *feat_f32_dev, int32_t feat_stride, void *stash_dev, int64_t stash_bytes,
+                               void *stream);
+int az_quick_heads_forward_f32(int32_t board_size, int32_t n_boards, const float *feat_dev, int32_t feat_stride, const void *w1p_dev,
+                               const float *b1p_dev, const void *w2p_dev, const float *b2p_dev, const void *w1v_dev,
+                               const float *b1v_dev, const float *w2v_dev, float b2v, float *logits_dev, float *values_dev, void *stream);
+
 /* The reference's two small example networks, one launch per evaluation, float32 on v_mfma_f32_16x16x4_f32 (the
  * reference's precision): examples/tictactoe/model.py (game AZ_GAME_TICTACTOE, input (B,9,3,3), 9 logits) and
  * examples/dots_and_boxes/model.py (game AZ_GAME_DAB, input (B,25,4,4), 24 logits); contract nn_models/base.py:17-19

@@ -282,3 +282,99 @@ def test_f32_tower_lookahead_under_random_flags(n, ch, blocks, G):
         assert torch.equal(v.view(-1)[on], vd[on]), name
         # (the heads kernel evaluates every row of the feature buffer: rows that are off keep stale FEATURES, so only the
         # flagged rows are specified; what must hold is that they equal the dense route bit for bit)
+
+
+@pytest.mark.parametrize("board,ch,blocks,layers,batch", [(15, 128, 1, 5, 300), (15, 128, 4, 5, 270), (15, 64, 2, 3, 1100), (15, 64, 3, 1, 33),
+                                                          (9, 64, 2, 5, 4200), (9, 64, 1, 2, 7), (15, 128, 2, 2, 5), (15, 64, 8, 5, 40)])
+def test_quick_tower_matches_fp32_forward(board, ch, blocks, layers, batch):
+    """The reference's QuickModel family (nn_models/quick_model.py, resnet_blocks.py:28-40; nets.QuickNet is pinned to the
+    reference's own QuickModel by tests/golden/quick.npz) on the f32 tower's QuickModel instantiation + az_quick_heads_forward_f32.
+    Same bar as the GomokuModel family: logits within 2e-5 of the logit scale of an f64 evaluation and no worse than 4x PyTorch's
+    own f32 forward; softmax priors within 1e-5 relative."""
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import QuickNet
+
+    torch.manual_seed(0)
+    net = _randomised(QuickNet(board, 9, ch, blocks, layers)).eval().cuda()
+    assert FusedTowerEvaluator.quick_shape(net) == (board, ch, blocks, layers) and FusedTowerEvaluator.supports(net)
+    ev = FusedTowerEvaluator(net, "f32")
+    x = torch.randint(-1, 2, (batch, 9, board, board), device="cuda").float()
+    x[:, 8] = torch.where(torch.rand(batch, 1, 1, device="cuda") < 0.5, -1.0, 1.0)
+    torch.backends.cudnn.allow_tf32 = False
+    with torch.inference_mode():
+        ref_p, ref_v = net(x)
+        ref64_p, ref64_v = net.double()(x.double())
+    net.float()
+    p, v = ev(x.contiguous())
+    assert p.shape == ref_p.shape and v.shape == ref_v.shape and p.dtype == torch.float32
+    scale = float(ref_p.abs().max())
+    err = float((p - ref64_p).abs().max())
+    err_torch = float((ref_p - ref64_p).abs().max())
+    assert err <= 2e-5 * scale + 2e-6, (err, scale)
+    assert float((v - ref64_v).abs().max()) <= 2e-5
+    assert err <= 4 * err_torch + 2e-6
+    pr, pr64 = torch.softmax(p.double(), 1), torch.softmax(ref64_p, 1)
+    assert float(((pr - pr64).abs() / pr64).max()) <= 1e-5 * max(1.0, scale)
+    # deterministic per board: a second launch (other tickets, other workgroups, a stash full of the first launch's data) and a
+    # permuted batch give the same rows bit for bit
+    p1, v1 = p.clone(), v.clone()
+    perm = torch.randperm(batch, device="cuda")
+    p2, v2 = ev(x[perm].contiguous())
+    assert torch.equal(p2, p1[perm]) and torch.equal(v2, v1[perm])
+
+
+def test_quick_tower_rejects_what_it_does_not_implement():
+    from alphazero_amd.engine import EngineError
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import QuickNet
+
+    assert FusedTowerEvaluator.quick_shape(QuickNet(15, 9, 96, 1, 5)) is None       # width
+    assert FusedTowerEvaluator.quick_shape(QuickNet(9, 9, 128, 1, 5)) is None        # 128 channels exist for 15x15
+    assert FusedTowerEvaluator.quick_shape(QuickNet(3, 9, 64, 1, 5)) is None         # the reference's own tic-tac-toe instance
+    assert FusedTowerEvaluator.quick_shape(QuickNet(15, 9, 64, 9, 5)) is None        # 45 conv layers
+    assert FusedTowerEvaluator.quick_shape(QuickNet(15, 9, 64, 2, 5, features=32)) is None
+    with pytest.raises(EngineError):
+        FusedTowerEvaluator(QuickNet(15, 9, 64, 1, 2).eval().cuda(), "bf16")
+
+
+@pytest.mark.parametrize("n,ch,blocks,layers,G", [(15, 128, 1, 3, 1100), (15, 64, 2, 2, 2100), (9, 64, 1, 5, 5300)])
+def test_quick_tower_packed_flags_equals_dense(n, ch, blocks, layers, G):
+    """QuickModel instantiation of the f32 tower on the engine's packed leaf batch with every kind of flag pattern (several
+    tickets per workgroup, look-ahead of the next board under the running one) == the dense route, row by row"""
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import QuickNet
+
+    torch.manual_seed(12)
+    ev = FusedTowerEvaluator(_randomised(QuickNet(n, 9, ch, blocks, layers)).eval().cuda(), "f32")
+    gen = torch.Generator().manual_seed(6)
+    stones = torch.randint(-1, 2, (G, 8, n * n), generator=gen)
+    player = torch.randint(0, 2, (G,), generator=gen) * 2 - 1
+    wc = (n * n + 31) // 32
+    bits = torch.zeros(G, 8, 2, 32 * wc, dtype=torch.int64)
+    bits[:, :, 0, :n * n] = (stones == 1).long()
+    bits[:, :, 1, :n * n] = (stones == -1).long()
+    w = (bits.view(G, 8, 2, wc, 32) << torch.arange(32)).sum(-1)
+    ring = (w.view(G, 16 * wc).to(torch.int64).cuda() & 0xFFFFFFFF).to(torch.int64)
+    ring32 = torch.where(ring >= 2 ** 31, ring - 2 ** 32, ring).to(torch.int32).contiguous()
+    leaf = torch.zeros(G, 4, dtype=torch.int32)
+    leaf[:, 3] = player.int()
+    leaf = leaf.cuda()
+    x = torch.cat([stones.view(G, 8, n, n).float(), player.view(G, 1, 1, 1).float().expand(G, 1, n, n)], 1).cuda().contiguous()
+    pd, vd = ev(x)
+    pd, vd = pd.clone(), vd.clone().view(-1)
+    patterns = {
+        "all": torch.ones(G, dtype=torch.uint8),
+        "half": (torch.rand(G, generator=gen) < 0.5).to(torch.uint8),
+        "sparse": (torch.rand(G, generator=gen) < 0.03).to(torch.uint8),
+        "runs": ((torch.arange(G) // 97) % 2).to(torch.uint8),
+        "last_only": torch.zeros(G, dtype=torch.uint8).index_fill_(0, torch.tensor([G - 1]), 1),
+        "none": torch.zeros(G, dtype=torch.uint8),
+    }
+    for name, fl in patterns.items():
+        flg = fl.cuda()
+        logits = torch.full((G, n * n), 77.0, device="cuda")
+        _, v = ev(None, logits_out=logits, packed=(ring32.data_ptr(), leaf.data_ptr(), None, None, flg.data_ptr()), n_boards=G)
+        torch.cuda.synchronize()
+        on = flg.bool()
+        assert torch.equal(logits[on], pd[on]), name
+        assert torch.equal(v.view(-1)[on], vd[on]), name
