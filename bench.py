@@ -46,6 +46,10 @@ WORKLOADS = {
     # 1.39 GFLOP per evaluation; and the same depth at 64 channels), both on the fused MFMA kernel
     "gomoku15_deep": (2, 15, 800, 16384, dict(board_size=15, channels=128, blocks=10)),
     "gomoku15_deep64": (2, 15, 800, 16384, dict(board_size=15, channels=64, blocks=10)),
+    # configs[4] as written -- "quick_model scaled up": the reference's QuickModel (nn_models/quick_model.py; nets.QuickNet) on the
+    # 15x15 board with its default 128 channels and 5-layer residual blocks, RESNET_BLOCK_NUM 1 -> 4: 21 conv layers like
+    # gomoku15_deep, plus the 3x3 head convs; f32 on the tower kernel's QuickModel instantiation
+    "gomoku15_quick": (2, 15, 800, 16384, dict(board_size=15, channels=128, blocks=4, layers=5)),
     "dab": (1, 3, 80, 3000, {}),
     "tictactoe": (0, 3, 50, 1000, {}),
 }
@@ -58,7 +62,8 @@ def make_model(workload: str):
     torch.manual_seed(0)
     game = WORKLOADS[workload][0]
     if game == 2:
-        return nets.GomokuNet(**WORKLOADS[workload][4]).eval()
+        kw = WORKLOADS[workload][4]
+        return (nets.QuickNet(**kw) if "layers" in kw else nets.GomokuNet(**kw)).eval()
     return (nets.DotsAndBoxesNet() if game == 1 else nets.TicTacToeNet()).eval()
 
 
@@ -156,6 +161,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
         kw_ = WORKLOADS[args.workload][4]
         f32_ok = kw_.get("channels") == 64 or (kw_.get("channels") == 128 and kw_.get("board_size") == 15)
         ok = FusedTowerEvaluator.supports(model) and (tdtype == torch.bfloat16 or (tdtype == torch.float32 and f32_ok))
+        ok = ok and (tdtype == torch.float32 or FusedTowerEvaluator.quick_shape(model) is None)  # QuickModel family: f32 tower only
         ok = ok or (game != 2 and tdtype == torch.float32 and SmallNetEvaluator.supports(model))  # az_smallnet.hip (f32 only)
         evaluator = "fused" if ok else "model"
     run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))
@@ -421,6 +427,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
                    "flops_per_eval": flops_per_eval, "boards_per_batch": evals_per_launch,
                    "share_of_step": nn_ms / max(nn_ms + tree_ms, 1e-9),
                    "implementation": (("az_smallnet.hip: k_smallnet_f32 (the whole network, one f32 MFMA kernel)" if game != 2 else
+                                       "az_tower_f32.hip: k_tower_f32_t16<QuickModel> (f32 MFMA conv tower, 16-cell tiles, 3x3 head convs) + k_quick_heads_f32"
+                                       if "layers" in WORKLOADS[args.workload][4] else
                                        "az_tower_f32.hip: k_tower_f32_t16 (f32 MFMA conv tower, 16-cell tiles) + k_heads_f32" if dtype_name == "f32" else
                                        "az_tower.hip: k_tower (fused bf16 MFMA conv tower) + k_heads (MFMA head linears)")
                                       if evaluator == "fused" else "PyTorch/MIOpen module forward")}
@@ -613,7 +621,8 @@ def main():
     out = measure(args, primary, args.steps, args.warmup, dev, rank, world, use_dist)
     sec_steps = args.secondary_steps if args.secondary_steps >= 0 else (min(args.steps, 4) if world == 1 else 0)
     second = None
-    if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1:
+    if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1 \
+            and "layers" not in kw:  # (the QuickModel family has no bf16 tower)
         second = measure(args, "bf16", sec_steps, 1, dev, rank, world, use_dist)
     if rank == 0:
         out["cpu_baseline"] = cpu
