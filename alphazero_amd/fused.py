@@ -127,6 +127,23 @@ class FusedTowerEvaluator:
         except Exception:
             return False
 
+    @staticmethod
+    def precision_for(model: nn.Module, dtype: torch.dtype):
+        """"bf16" / "f32" when a hand-written tower evaluates this module at this engine dtype, else None (the module's own
+        PyTorch forward runs): GomokuModel family in bf16 (64 / 128 channels) and f32 (64 channels; 128 on 15x15), QuickModel
+        family in f32"""
+        if not FusedTowerEvaluator.supports(model):
+            return None
+        q = FusedTowerEvaluator.quick_shape(model)
+        if q is not None:
+            return "f32" if dtype == torch.float32 else None
+        if dtype == torch.bfloat16:
+            return "bf16"
+        if dtype != torch.float32:
+            return None
+        ch, n2 = model._shared_layers[0].out_channels, model._policy_head[4].in_features
+        return "f32" if ch == 64 or (ch == 128 and n2 == 225) else None
+
     def __init__(self, model: nn.Module, precision: str = "bf16"):
         """precision: "bf16" (az_tower.hip: bf16 operands, f32 accumulation -- the throughput mode) or "f32"
         (az_tower_f32.hip: f32 MFMA, the reference's own arithmetic, 64-channel trunks).  The weights are folded and

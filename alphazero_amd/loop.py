@@ -47,7 +47,7 @@ class SelfPlayTrainLoop:
             if fused is None:
                 from .fused import FusedTowerEvaluator
 
-                fused = nn_dtype == torch.bfloat16 and FusedTowerEvaluator.supports(self.player)
+                fused = FusedTowerEvaluator.precision_for(self.player, nn_dtype) is not None
             runner = SelfPlayRunner(self.engine, self.player, num_sims, fused=bool(fused))
         self.runner = runner
         self.ring = ring if ring is not None else DeviceSampleRing(self.engine, ring_capacity)

@@ -158,10 +158,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     if evaluator == "auto":
         from alphazero_amd.fused import FusedTowerEvaluator, SmallNetEvaluator
 
-        kw_ = WORKLOADS[args.workload][4]
-        f32_ok = kw_.get("channels") == 64 or (kw_.get("channels") == 128 and kw_.get("board_size") == 15)
-        ok = FusedTowerEvaluator.supports(model) and (tdtype == torch.bfloat16 or (tdtype == torch.float32 and f32_ok))
-        ok = ok and (tdtype == torch.float32 or FusedTowerEvaluator.quick_shape(model) is None)  # QuickModel family: f32 tower only
+        ok = FusedTowerEvaluator.precision_for(model, tdtype) is not None  # (QuickModel family: f32 tower only)
         ok = ok or (game != 2 and tdtype == torch.float32 and SmallNetEvaluator.supports(model))  # az_smallnet.hip (f32 only)
         evaluator = "fused" if ok else "model"
     run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))

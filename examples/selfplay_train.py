@@ -19,7 +19,11 @@ def main():
     ap.add_argument("--moves", type=int, default=10)
     ap.add_argument("--slots", type=int, default=16384)
     ap.add_argument("--sims", type=int, default=800)
-    ap.add_argument("--blocks", type=int, default=10)
+    ap.add_argument("--net", default="gomoku", choices=["gomoku", "quick"], help="gomoku: the GomokuModel family (--blocks residual "
+                    "blocks of two convs; bf16 tower by default); quick: the reference's QuickModel family (--blocks blocks of --layers "
+                    "convs, the f32 tower -- the reference's precision)")
+    ap.add_argument("--blocks", type=int, default=0, help="0 = 10 (gomoku) / 4 (quick): 21 conv layers either way")
+    ap.add_argument("--layers", type=int, default=5, help="conv layers per residual block of the QuickModel family")
     ap.add_argument("--channels", type=int, default=128, choices=[64, 128], help="trunk width (both run on the fused MFMA tower)")
     ap.add_argument("--board", type=int, default=15, choices=[9, 15])
     ap.add_argument("--batch", type=int, default=1024)
@@ -29,7 +33,7 @@ def main():
     import torch.distributed as dist
 
     from alphazero_amd.loop import SelfPlayTrainLoop
-    from alphazero_amd.nets import GomokuNet
+    from alphazero_amd.nets import GomokuNet, QuickNet
 
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     torch.cuda.set_device(local)
@@ -38,8 +42,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(1234 + rank)
-    loop = SelfPlayTrainLoop(GomokuNet(args.board, args.channels, args.blocks), 2, args.board, args.slots, args.sims, dev,
-                             batch_size=args.batch, train_steps_per_move=args.train_steps_per_move)
+    if args.net == "quick":
+        net, dt_ = QuickNet(args.board, 9, args.channels, args.blocks or 4, args.layers), torch.float32
+    else:
+        net, dt_ = GomokuNet(args.board, args.channels, args.blocks or 10), torch.bfloat16
+    loop = SelfPlayTrainLoop(net, 2, args.board, args.slots, args.sims, dev, batch_size=args.batch,
+                             train_steps_per_move=args.train_steps_per_move, nn_dtype=dt_)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = loop.run(args.moves)
