@@ -221,7 +221,13 @@ class ChessArena:
 
     def __init__(self, model_cls, game_cls, device: Optional[torch.device] = None, *, n_slots: int = 1024,
                  num_simulation: int = TRAIN_NUM_SIMULATION, c_puct: float = C_PUCT, epsilon: float = EPSILON,
-                 alpha: float = ALPHA, nn_dtype: torch.dtype = torch.float32) -> None:
+                 alpha: float = ALPHA, nn_dtype: torch.dtype = torch.float32, fused: Optional[bool] = False,
+                 use_graph: bool = False) -> None:
+        """``fused``: False (default) = the module's own PyTorch-ROCm forward, whatever the module is -- a seeded run then
+        replays a seeded reference run move for move; True = the hand-written network kernels (alphazero_amd.fused: f32 towers
+        at nn_dtype float32 -- the reference's arithmetic, agreeing with the module's forward to f32 rounding --, the bf16
+        tower at bfloat16; raises if none covers the module); None = use them when one covers the module.  ``use_graph``:
+        replay the simulation step as a HIP graph (what the small, launch-bound games want)."""
         if not torch.cuda.is_available():
             raise EngineError("alphazero_amd.ChessArena needs a GPU (no CPU fallback)")
         # the reference defaults to SELF_PLAY_DEVICE = "cpu" (config/train_config.py:11); here the GPU is the point
@@ -233,6 +239,7 @@ class ChessArena:
         self.game_id, self.board_size = resolve_game(game_cls)
         self.num_simulation, self.c_puct, self.epsilon, self.alpha = num_simulation, c_puct, epsilon, alpha
         self.n_slots, self.nn_dtype = n_slots, nn_dtype
+        self.fused, self.use_graph = fused, use_graph
         self._engines: dict[int, Engine] = {}
         self.games_played = 0
 
@@ -269,7 +276,15 @@ class ChessArena:
         and the slots restarted -- enough to replay every game elsewhere (the parity tests do, on the CPU oracle)."""
         slots = min(slots or self.n_slots, n_games)
         eng = self._engine(slots)
-        run = SelfPlayRunner(eng, self.model, self.num_simulation, alpha=self.alpha, reference_rng=reference_rng)
+        fused = self.fused
+        if fused is None:
+            from .fused import evaluator_available
+
+            fused = evaluator_available(self.game_id, self.model, self.nn_dtype)
+        # (a new runner per call: a fused evaluator folds and packs the module's CURRENT weights here, so a load_model /
+        # state_dict refresh between calls is picked up)
+        run = SelfPlayRunner(eng, self.model, self.num_simulation, alpha=self.alpha, reference_rng=reference_rng, fused=bool(fused),
+                             use_graph=self.use_graph)
         d = eng.dims
 
         def tao_of(i: int) -> float:

@@ -474,3 +474,12 @@ class SmallNetEvaluator:
                 ev1.record()
                 self.kernel_events.append((ev0, ev1))
         return logits, value.view(B, 1)
+
+
+def evaluator_available(game_id: int, model: nn.Module, dtype: torch.dtype) -> bool:
+    """True when one of the hand-written network kernels evaluates ``model`` for an engine of this game and nn_dtype
+    (``SelfPlayRunner(..., fused=True)`` will then construct it): the GomokuModel / QuickModel towers for gomoku, the
+    one-kernel f32 networks for tic-tac-toe (0) and dots-and-boxes (1)"""
+    if game_id == 2:
+        return FusedTowerEvaluator.precision_for(model, dtype) is not None
+    return dtype == torch.float32 and SmallNetEvaluator.game_of(model) == game_id

@@ -27,14 +27,18 @@ def sync_model_from_shared(model: torch.nn.Module, model_state: dict, lock: Any)
 
 def gpu_self_player_worker(model_cls, game_cls, model_state, experience_pool, num_self_play_games: int, worker_id: int,
                            model_lock: Any, *, seed_bias: int = 0, n_slots: int = 1024, num_simulation: int = 80,
-                           device: torch.device | None = None, trace: list | None = None) -> None:
+                           device: torch.device | None = None, trace: list | None = None, fused: bool | None = False,
+                           use_graph: bool = False, nn_dtype: torch.dtype = torch.float32) -> None:
+    """``fused`` / ``use_graph`` / ``nn_dtype``: as for ChessArena (fused=None: the hand-written f32 / bf16 network kernels when
+    they cover ``model_cls``, else its own forward)."""
     try:
         seed = seed_bias + worker_id
         random.seed(seed)
         torch.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
         dev = device or torch.device("cuda", worker_id % max(torch.cuda.device_count(), 1))
-        arena = ChessArena(model_cls, game_cls, dev, n_slots=n_slots, num_simulation=num_simulation)
+        arena = ChessArena(model_cls, game_cls, dev, n_slots=n_slots, num_simulation=num_simulation, fused=fused, use_graph=use_graph,
+                           nn_dtype=nn_dtype)
         sync_model_from_shared(arena.model, model_state, model_lock)
         # one "generation" = n_slots concurrent games at the temperature the reference's worker would use for its
         # generation-th game; weights are refreshed every SELF_PLAY_UPDATE_MODEL_FREQUENCY generations' worth of games

@@ -212,12 +212,13 @@ def test_copy_to_host_moves_every_byte():
         copy_to_host(torch.zeros(4), torch.zeros(4, device="cuda"))  # not pinned
 
 
-def _replay_trace(oracle, trace, pool_items, game, n, A, sims, slots, tao_of_game, max_plies):
+def _replay_trace(oracle, trace, pool_items, game, n, A, sims, slots, tao_of_game, max_plies, ev=None):
     """Rebuild every game of a traced self_play_many run (per-slot draws of every move round, recycling included) and
     replay it on the CPU oracle: actions, the samples the pool received (put order: finished games in slot order per
     round, last position first) and z must agree bit for bit.  training/self_play.py:30-139."""
     d = oracle.dims(game, n)
-    ev = oracle.torch_eval(HashNet(A, 5.0), (d["cin"], d["H"], d["W"]))
+    if ev is None:
+        ev = oracle.torch_eval(HashNet(A, 5.0), (d["cin"], d["H"], d["W"]))
     cur = {s: {"noise": [], "expo": [], "actions": [], "game": s} for s in range(slots)}
     next_game = slots
     k = 0  # cursor into pool_items
@@ -295,6 +296,45 @@ def test_gpu_worker_replays_on_the_oracle(oracle):
                            num_simulation=sims, trace=trace)
     tao_of = lambda i: reference_tao(i // slots)
     assert _replay_trace(oracle, trace, pool.items, 1, 3, A, sims, slots, tao_of, 24) == n_games
+
+
+@pytest.mark.parametrize("name", ["dab", "gomoku9-quick"])
+def test_gpu_worker_with_the_fused_f32_networks_replays_on_the_oracle(oracle, name):
+    """f-1 on the fast path: gpu_self_player_worker(fused=None) picks the hand-written f32 network kernel for the reference's
+    dots-and-boxes network (HIP-graph replay of the simulation step) and for a QuickModel-family gomoku network; every game
+    is replayed on the oracle with that same kernel as the oracle's evaluator (one dense position per call): actions,
+    samples, z bit for bit."""
+    import threading
+
+    from alphazero_amd import nets
+    from alphazero_amd.arena import reference_tao
+    from alphazero_amd.fused import FusedTowerEvaluator, SmallNetEvaluator
+    from alphazero_amd.games import DotsAndBoxesGame, Gomoku9Game
+    from alphazero_amd.worker import gpu_self_player_worker
+
+    from .test_gpu_bench_path import _tower_callback
+    from .test_gpu_tower import _randomised
+
+    torch.manual_seed(21)
+    if name == "dab":
+        game, n, A, sims, slots, n_games, max_plies, game_cls = 1, 3, 24, 16, 5, 11, 24, DotsAndBoxesGame
+        proto = nets.DotsAndBoxesNet().eval()
+        model_cls = nets.DotsAndBoxesNet
+        make_ev = SmallNetEvaluator
+    else:
+        game, n, A, sims, slots, n_games, max_plies, game_cls = 2, 9, 81, 12, 4, 6, 81, Gomoku9Game
+        proto = _randomised(nets.QuickNet(9, 9, 64, 1, 2)).eval()
+        model_cls = functools.partial(nets.QuickNet, 9, 9, 64, 1, 2)
+        make_ev = lambda m: FusedTowerEvaluator(m, "f32")
+    shared = {k: v.clone() for k, v in proto.state_dict().items()}
+    pool, trace = ListPool(), []
+    gpu_self_player_worker(model_cls, game_cls, shared, pool, n_games, 0, threading.Lock(), n_slots=slots, num_simulation=sims,
+                           trace=trace, fused=None, use_graph=(name == "dab"))
+    d = oracle.dims(game, n)
+    cb, calls = _tower_callback(make_ev(proto.cuda()), (d["cin"], d["H"], d["W"]), torch.float32)
+    tao_of = lambda i: reference_tao(i // slots)
+    assert _replay_trace(oracle, trace, pool.items, game, n, A, sims, slots, tao_of, max_plies, ev=cb) == n_games
+    assert calls[0] > 0
 
 
 class _RefLikeRing:
