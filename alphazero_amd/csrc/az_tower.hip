@@ -435,6 +435,77 @@ __device__ __forceinline__ void heads_from_acc(const float *hw, float *hp, int l
   }
 }
 
+// QuickModel family (nn_models/resnet_blocks.py:28-40): the last layer of a block writes relu(conv) + x, x = the block's input
+// (kept in registers as packed bf16 since the block's first layer, like the GomokuModel block's residual), and is not
+// activated again.  The sum is taken in f32 and rounded to bf16 once.
+template <int NPT, int C>
+__device__ __forceinline__ void epilogue_add(char *act, int lane, int cot0, const int (&pp)[NPT], const bool (&ok)[NPT],
+                                             const f32x16 (&acc)[NPT][2], const uint2 (&res)[NPT][2][4]) {
+  const int h = fresh(lane) >> 5;
+#pragma unroll
+  for (int pt = 0; pt < NPT; ++pt) {
+    const int pe = fresh(pp[pt]);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint2 rr = res[pt][ct][q];
+        const f32x2 a = {fmaxf(acc[pt][ct][4 * q + 0], 0.0f) + bf_lo(rr.x), fmaxf(acc[pt][ct][4 * q + 1], 0.0f) + bf_hi(rr.x)};
+        const f32x2 b = {fmaxf(acc[pt][ct][4 * q + 2], 0.0f) + bf_lo(rr.y), fmaxf(acc[pt][ct][4 * q + 3], 0.0f) + bf_hi(rr.y)};
+        const uint2 v = make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2)),
+                                   __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2)));
+        if (ok[pt]) *(uint2 *)(act + act_addr<C>(pe, (cot0 + ct) * 4 + q) + 8 * h) = v;
+      }
+  }
+}
+
+// QuickModel heads: the three 3x3 head convs (2 policy channels, 1 value channel; BN folded, ReLU) from the finished bf16
+// activations in LDS, on the VALU in f32: thread m < NVT takes cell m and 64 of its channels (C = 128: waves 4..7 take the upper
+// 64 and hand their partial sums over through `hp`); the filters hq [3][9 taps][C] f32 come through the scalar cache (the
+// channel split is wave-uniform).  Ends with a workgroup barrier: every read of `act` is done before the next board's input
+// is expanded over it.  Feature rows, bf16: [policy0 NV | policy1 NV | pad to 16 | value NV | pad to 16].
+template <int N, int NVT, int NW, int ZERO_OFF, int C>
+__device__ __forceinline__ void heads_quick(const char *act, const float *__restrict__ hq, const float *hw, float *hp, int tid_, int wave,
+                                            const int *slots, uint16_t *feat, int FS) {
+  constexpr int NV = N * N, KPQ = (2 * NV + 15) / 16 * 16;
+  static_assert(NVT <= 256 && (NW == 4 || NW == 8), "one thread per cell and 64-channel split");
+  const int m = fresh(tid_) & 255, split = wave >> 2;  // (C = 64: split is 0)
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+  const bool live = m < NVT;
+  const int mc = live ? m : 0, cell = mc % NV, row = cell / N, col = cell - row * N;
+  const float *wq = hq + split * 64;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dr = tap / 3 - 1, dc = tap - (tap / 3) * 3 - 1, rr = row + dr, cc = col + dc;
+    const bool on = live && rr >= 0 && rr < N && cc >= 0 && cc < N;
+    const int q = mc + dr * N + dc;
+    const float *wt = wq + tap * C;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {  // 16-byte chunk = 8 channels
+      const uint4 a = *(const uint4 *)(act + (on ? act_addr<C>(q, split * 8 + ch) : ZERO_OFF + (ch << 4)));
+      const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bf_lo(aw[e]), hi = bf_hi(aw[e]);
+        const int c0 = ch * 8 + 2 * e;
+        s0 = fmaf(lo, wt[c0], s0); s0 = fmaf(hi, wt[c0 + 1], s0);
+        s1 = fmaf(lo, wt[9 * C + c0], s1); s1 = fmaf(hi, wt[9 * C + c0 + 1], s1);
+        s2 = fmaf(lo, wt[18 * C + c0], s2); s2 = fmaf(hi, wt[18 * C + c0 + 1], s2);
+      }
+    }
+  }
+  if (NW == 8 && wave >= 4 && live) { hp[m] = s0; hp[256 + m] = s1; hp[512 + m] = s2; }
+  __syncthreads();
+  if (wave >= 4 || !live) return;
+  if (NW == 8) { s0 += hp[m]; s1 += hp[256 + m]; s2 += hp[512 + m]; }
+  const int g = slots[m / NV];
+  if (g < 0) return;
+  uint16_t *fr = feat + (size_t)g * FS;
+  fr[cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(s0 + hw[3 * C + 0], 0.0f));
+  fr[NV + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(s1 + hw[3 * C + 1], 0.0f));
+  fr[KPQ + cell] = __builtin_bit_cast(uint16_t, (__bf16)fmaxf(s2 + hw[3 * C + 2], 0.0f));
+}
+
 // async global -> LDS copy of 4 B per lane
 __device__ __forceinline__ void glds4(const void *g_lane, void *lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
@@ -445,14 +516,16 @@ __device__ __forceinline__ void glds4(const void *g_lane, void *lds_base) {
 // w0: [9][1][2][C][8] bf16 (first conv, 9 input channels padded to 16).  wl: [L][9][C/16][2][C][8] bf16.
 // bias: [1+L][C] f32.  headw: [3][C] f32 (policy, value0, value1), headb: [3].
 // feat: (G, FS) bf16 = the inputs of the heads' Linear layers (layout: see the heads' epilogue and k_heads).
-template <int N, int BPW, int NPT, int ST, int C>
+// QK = true: the reference's QuickModel family (nn_models/quick_model.py:67-93): L = n_blocks x BL layers of conv3x3 + BN + ReLU,
+// a block's input added back after its last ReLU (epilogue_add), 3x3 head convs (heads_quick); headw = [3][9][C] f32.
+template <int N, int BPW, int NPT, int ST, int C, bool QK = false>
 __global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) void k_tower(const uint16_t *__restrict__ x, const uint32_t *__restrict__ ring,
                                                const int4 *__restrict__ leafrec, const int32_t *__restrict__ list,
                                                const int32_t *__restrict__ count, const uint8_t *__restrict__ flags, int G,
                                                const char *__restrict__ w0,
                                                const char *__restrict__ wl, const float *__restrict__ bias, int L,
                                                const float *__restrict__ headw, const float *__restrict__ headb,
-                                               uint16_t *__restrict__ feat, int FS, unsigned int *tickets) {
+                                               uint16_t *__restrict__ feat, int FS, unsigned int *tickets, int BL) {
   using Q = Geo<N, BPW, NPT, ST, C>;
   constexpr int NW = Q::NW, KS = Q::KS, TAP_BYTES = Q::TAP_BYTES;
   constexpr int WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RG_STRIDE = Q::RG_BYTES, STAGE_BYTES = Q::STAGE_BYTES, NTH = NW * 64;
@@ -625,6 +698,37 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) voi
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    if constexpr (QK) {
+      // ---- QuickModel blocks (L >= 1): every layer conv + bias + ReLU in place; the block's input stays in `res` until its last layer
+      int j = 0;
+      for (int l = 0; l < L; ++l) {
+        if (j == 0) {
+          const int h = fresh(lane) >> 5;
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) {
+            const int pe = fresh(pp[pt]);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) res[pt][ct][q] = *(const uint2 *)(act + act_addr<C>(pe, (cot0 + ct) * 4 + q) + 8 * h);
+          }
+        }
+        init_acc<false, NPT>(bl + bslot * C + cot0 * 32, lane, acc, res);
+        bias_ahead(l + 1 < L ? 2 + l : 0);
+        if (l + 1 < L)
+          conv_layer<KS, KS, N, Q::ZERO_OFF, NPT, ST, NW, ST, STAGE_BYTES, C>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, wl + (size_t)(l + 1) * 9 * TAP_BYTES,
+                                           tid, lane, pp, vm, acc);
+        else  // the board's last layer: prefetch the next board's stem weights
+          conv_layer<KS, 1, N, Q::ZERO_OFF, NPT, ST, NW, ST0, STAGE_BYTES, C>(act, wbuf, buf, wl + (size_t)l * 9 * TAP_BYTES, w0, tid, lane, pp, vm, acc);
+        bias_step();
+        if (j == BL - 1) epilogue_add<NPT, C>(act, lane, cot0, pp, ok, acc, res);
+        else epilogue<NPT, C>(act, lane, cot0, pp, ok, acc);
+        __syncthreads();
+        if (l == 0) fetch(inb);  // the next group's packed input: lands under the rest of this group's tower
+        j = j + 1 == BL ? 0 : j + 1;
+      }
+      heads_quick<N, Q::NVT, NW, Q::ZERO_OFF, C>(act, headw, hw, hp, tid, wave, slots, feat, FS);
+    } else {
     // ---- residual blocks
     for (int l = 0; l < L; l += 2) {
       {  // res = this block's input
@@ -680,6 +784,7 @@ __global__ __launch_bounds__(C * 4, (C == 64 ? AZ_TOWER_WAVES_PER_SIMD : 1)) voi
     // 32 of its cell's 64 channels; the other half sits in lane ^ 32): 3 x 32 FMAs per cell on the VALU against the f32
     // filter table in LDS (broadcast reads), one cross-half exchange, then the bf16 rows of the heads' Linear inputs
     heads_from_acc<NPT, Q::NV, C>(hw, hp, lane, wave, pp, ok, slots, acc, feat, FS);
+    }  // !QK
     STAMP(28);
     STAMP(29);  // (no barrier: the last conv ended with one, and nothing has read act or the weight buffers since)
 #if AZ_TOWER_STAMP
@@ -812,6 +917,79 @@ __global__ __launch_bounds__(256, 2) void k_heads(const uint16_t *__restrict__ f
     }
     __syncthreads();
     if (tid < MT * 32 && g0 + tid < G) values[g0 + tid] = tanhf(vsum[0][tid] + vsum[1][tid] + b2);
+  }
+}
+
+// The QuickModel heads' Linear layers (nn_models/quick_model.py:138-154, 185-199 with config/quick_model_config.py's defaults)
+// on the bf16 feature rows [policy0 NV | policy1 NV | pad | value NV | pad]:
+//   logits = relu(feat[:, :2NV] @ W1p^T + b1p) @ W2p^T + b2p;   value = tanh(relu(feat[:, KPQ:KPQ+NV] @ W1v^T + b1v) @ w2v + b2v)
+// One workgroup = 32 boards.  Phase 1: wave w = hidden tile (w & 1) of head (w >> 1), a bf16 MFMA GEMM read straight from L2,
+// bias + ReLU into LDS (the policy's hidden units as bf16, the next GEMM's operand; the value's as f32).  Phase 2: the policy's
+// second layer as bf16 MFMA GEMMs from LDS (output tiles wave, wave + 4, ...), the value's as a k-ordered fmaf chain per board.
+// w1p [2][KPQ/16][2][32][8], w2p [ceil(NV/32)][4][2][32][8], w1v [2][KVQ/16][2][32][8] bf16, zero padded.
+template <int NV>
+__global__ __launch_bounds__(256, 2) void k_quick_heads(const uint16_t *__restrict__ feat, int FS, int G, const char *__restrict__ w1p,
+                                                        const float *__restrict__ b1p, const char *__restrict__ w2p,
+                                                        const float *__restrict__ b2p, const char *__restrict__ w1v,
+                                                        const float *__restrict__ b1v, const float *__restrict__ w2v, float b2v,
+                                                        float *__restrict__ logits, float *__restrict__ values) {
+  constexpr int KPQ = (2 * NV + 15) / 16 * 16, KVQ = (NV + 15) / 16 * 16, NTP = (NV + 31) / 32;
+  __shared__ __attribute__((aligned(16))) uint16_t hidp[32][72];  // rows of 144 bytes: 16-byte aligned, conflict-free b128 reads
+  __shared__ float hidv[32][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int g0 = blockIdx.x * 32;
+  const uint16_t *fa = feat + (size_t)min(g0 + r, G - 1) * FS + 8 * h;  // rows past the batch: a copy of the last row, not stored
+  {
+    const int head = wave >> 1, nt = wave & 1;
+    const int ksn = head == 0 ? KPQ / 16 : KVQ / 16;
+    const char *wb = (head == 0 ? w1p : w1v) + ((size_t)nt * ksn * 2 + h) * 512 + r * 16;
+    const uint16_t *fh = fa + (head == 0 ? 0 : KPQ);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int ks = 0; ks < ksn; ++ks) {
+      const bf16x8 b = *(const bf16x8 *)(wb + (size_t)ks * 1024);
+      const bf16x8 a = *(const bf16x8 *)(fh + ks * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    const int n = nt * 32 + r;
+    const float bn = (head == 0 ? b1p : b1v)[n];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      const float v = fmaxf(acc[i] + bn, 0.0f);
+      if (head == 0) hidp[row][n] = __builtin_bit_cast(uint16_t, (__bf16)v);
+      else hidv[row][n] = v;
+    }
+  }
+  __syncthreads();
+  for (int nt = wave; nt < NTP; nt += 4) {
+    const char *wb = w2p + ((size_t)nt * 4 * 2 + h) * 512 + r * 16;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 b = *(const bf16x8 *)(wb + (size_t)ks * 1024);
+      const bf16x8 a = *(const bf16x8 *)(&hidp[r][ks * 16 + 8 * h]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    const int n = nt * 32 + r;
+    if (n < NV) {
+      const float bias = b2p[n];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (g0 + row < G) logits[(size_t)(g0 + row) * NV + n] = acc[i] + bias;
+      }
+    }
+  }
+  if (tid < 32 && g0 + tid < G) {
+    float t = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) t = fmaf(hidv[tid][k], w2v[k], t);
+    values[g0 + tid] = tanhf(t + b2v);
   }
 }
 
@@ -988,7 +1166,7 @@ int az_tower_forward(int32_t board_size, int32_t channels, int32_t n_boards, int
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
                        (const int4 *)packed_leaf_dev, (const int32_t *)(use_list ? list_dev : nullptr),
                        (const int32_t *)(use_list ? count_dev : nullptr), (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev,
-                       n_conv_layers, headw_dev, headb_dev, (uint16_t *)feat_bf16_dev, (int)feat_stride, tickets);
+                       n_conv_layers, headw_dev, headb_dev, (uint16_t *)feat_bf16_dev, (int)feat_stride, tickets, 2);
     return AZ_OK;
   };
   // 64 channels: 4 waves, two workgroups per CU.  128 channels: 8 waves (two sets of four, 64 output channels each), one
@@ -1058,6 +1236,95 @@ int az_tower_heads_forward_static(int32_t board_size, int32_t channels, int32_t 
   if (rc != AZ_OK) return rc;
   return az_heads_forward(board_size, n_boards, feat, stride, wp_dev, bp_dev, w1_dev, b1_dev, w2_dev, b2, logits_dev, values_dev,
                           stream);
+}
+
+int az_quick_tower_forward(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_blocks, int32_t block_layers,
+                           const void *x_bf16_dev, const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev,
+                           const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev, const float *headb_dev,
+                           void *feat_bf16_dev, int32_t feat_stride, void *stream) {
+  using namespace aztower;
+  if ((!x_bf16_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !wl_dev || !bias_dev || !headw_dev || !headb_dev || !feat_bf16_dev) {
+    g_tower_err = "null argument";
+    return AZ_EINVAL;
+  }
+  if (n_boards < 1 || n_blocks < 1 || block_layers < 1 || (int64_t)n_blocks * block_layers > 1024) {
+    g_tower_err = "quick tower: n_boards >= 1, n_blocks >= 1, block_layers >= 1";
+    return AZ_EINVAL;
+  }
+  if ((board_size != 9 && board_size != 15) || (channels != 64 && channels != 128)) { g_tower_err = "board_size must be 9 or 15, channels 64 or 128"; return AZ_EINVAL; }
+  if (feat_stride < az_heads_feat_stride(board_size)) { g_tower_err = "feat_stride below az_heads_feat_stride(board_size)"; return AZ_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  int dev = 0, cur = 0;
+  if (tower_device(s, &dev) != 0 || dev < 0 || dev >= 64) { g_tower_err = "cannot tell the stream's device"; return AZ_EHIP; }
+  if (hipGetDevice(&cur) != hipSuccess) { g_tower_err = "hipGetDevice failed"; return AZ_EHIP; }
+  struct DeviceGuard {
+    int back;
+    DeviceGuard(int want, int cur_) : back(want != cur_ ? cur_ : -1) { if (back >= 0) (void)hipSetDevice(want); }
+    ~DeviceGuard() { if (back >= 0) (void)hipSetDevice(back); }
+  } guard(dev, cur);
+  unsigned int *tickets = tower_tickets(dev, s);
+  if (tickets == nullptr) return AZ_EHIP;
+  const int L = n_blocks * block_layers;
+  auto launch = [&](auto kern, size_t lds, int bpw, int nw, int wg_per_cu, int variant) -> int {
+    if (lds * wg_per_cu > 160 * 1024) { g_tower_err = "tower geometry exceeds the CU's LDS"; return AZ_EINVAL; }
+    {
+      std::lock_guard<std::mutex> lock(g_ticket_mutex);
+      if (!(g_td[dev].attr_done & (1u << variant))) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          g_tower_err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+          return AZ_EHIP;
+        }
+        g_td[dev].attr_done |= 1u << variant;
+      }
+    }
+    const int groups = (n_boards + bpw - 1) / bpw, cap = 256 * wg_per_cu;
+    const int grid = groups < cap ? groups : cap;
+    const bool use_flags = !x_bf16_dev && flags_dev;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, (const uint16_t *)x_bf16_dev, (const uint32_t *)packed_ring_dev,
+                       (const int4 *)packed_leaf_dev, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                       (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)w0_dev, (const char *)wl_dev, bias_dev, L,
+                       headw_dev, headb_dev, (uint16_t *)feat_bf16_dev, (int)feat_stride, tickets, (int)block_layers);
+    return AZ_OK;
+  };
+  int rc;
+  if (channels == 64) {
+    using G15 = Geo<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, 64>;
+    using G9 = Geo<9, 3, 2, AZ_TOWER9_ST, 64>;
+    if (board_size == 15) rc = launch(k_tower<15, AZ_TOWER15_BPW, AZ_TOWER15_NPT, AZ_TOWER15_ST, 64, true>, G15::lds_bytes(), AZ_TOWER15_BPW, G15::NW, AZ_TOWER_WAVES_PER_SIMD, 4);
+    else rc = launch(k_tower<9, 3, 2, AZ_TOWER9_ST, 64, true>, G9::lds_bytes(), 3, G9::NW, AZ_TOWER_WAVES_PER_SIMD, 5);
+  } else {
+    using G15 = Geo<15, 1, 2, 1, 128>;
+    using G9 = Geo<9, 3, 2, 1, 128>;
+    if (board_size == 15) rc = launch(k_tower<15, 1, 2, 1, 128, true>, G15::lds_bytes(), 1, G15::NW, 1, 6);
+    else rc = launch(k_tower<9, 3, 2, 1, 128, true>, G9::lds_bytes(), 3, G9::NW, 1, 7);
+  }
+  if (rc != AZ_OK) return rc;
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) { g_tower_err = std::string("k_tower (quick) launch: ") + hipGetErrorString(err); return AZ_EHIP; }
+  return AZ_OK;
+}
+
+int az_quick_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16_dev, int32_t feat_stride, const void *w1p_dev,
+                           const float *b1p_dev, const void *w2p_dev, const float *b2p_dev, const void *w1v_dev, const float *b1v_dev,
+                           const float *w2v_dev, float b2v, float *logits_dev, float *values_dev, void *stream) {
+  using namespace aztower;
+  if (!feat_bf16_dev || !w1p_dev || !b1p_dev || !w2p_dev || !b2p_dev || !w1v_dev || !b1v_dev || !w2v_dev || !logits_dev || !values_dev) {
+    g_tower_err = "null argument";
+    return AZ_EINVAL;
+  }
+  if (n_boards < 1 || (board_size != 9 && board_size != 15)) { g_tower_err = "n_boards >= 1, board_size 9 or 15"; return AZ_EINVAL; }
+  if (feat_stride < az_heads_feat_stride(board_size) || (feat_stride & 7)) { g_tower_err = "feat_stride: a multiple of 8, at least az_heads_feat_stride(board_size)"; return AZ_EINVAL; }
+  const dim3 grid((n_boards + 31) / 32), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (board_size == 15)
+    hipLaunchKernelGGL((k_quick_heads<225>), grid, block, 0, s, (const uint16_t *)feat_bf16_dev, (int)feat_stride, (int)n_boards, (const char *)w1p_dev,
+                       b1p_dev, (const char *)w2p_dev, b2p_dev, (const char *)w1v_dev, b1v_dev, w2v_dev, b2v, logits_dev, values_dev);
+  else
+    hipLaunchKernelGGL((k_quick_heads<81>), grid, block, 0, s, (const uint16_t *)feat_bf16_dev, (int)feat_stride, (int)n_boards, (const char *)w1p_dev,
+                       b1p_dev, (const char *)w2p_dev, b2p_dev, (const char *)w1v_dev, b1v_dev, w2v_dev, b2v, logits_dev, values_dev);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) { g_tower_err = std::string("k_quick_heads launch: ") + hipGetErrorString(err); return AZ_EHIP; }
+  return AZ_OK;
 }
 
 }  // extern "C"

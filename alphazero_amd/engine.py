@@ -43,7 +43,7 @@ EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check"
            "az_reset_stats", "az_eval_hash", "az_tower_forward", "az_tower_last_error", "az_heads_forward", "az_heads_feat_stride", "az_augment_samples", "az_leaf_buffers", "az_compact_leaves", "az_copy_to_host",
            "az_tower_heads_forward_static", "az_static_max_boards", "az_tower_forward_f32", "az_heads_forward_f32",
            "az_select_wave", "az_expand_wave", "az_search_remaining", "az_set_virtual_loss", "az_smallnet_forward_f32",
-           "az_quick_tower_forward_f32", "az_quick_heads_forward_f32", "az_quick_stash_bytes",
+           "az_quick_tower_forward_f32", "az_quick_heads_forward_f32", "az_quick_stash_bytes", "az_quick_tower_forward", "az_quick_heads_forward",
            "az_smallnet_head_floats"]
 
 _lib = None
@@ -100,6 +100,8 @@ def load_library() -> C.CDLL:
     lib.az_quick_stash_bytes.restype = C.c_int64
     lib.az_quick_tower_forward_f32.argtypes = [C.c_int32] * 5 + [vp] * 10 + [C.c_int32, vp, C.c_int64, vp]
     lib.az_quick_heads_forward_f32.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32] + [vp] * 7 + [C.c_float, vp, vp, vp]
+    lib.az_quick_tower_forward.argtypes = [C.c_int32] * 5 + [vp] * 10 + [C.c_int32, vp]
+    lib.az_quick_heads_forward.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32] + [vp] * 7 + [C.c_float, vp, vp, vp]
     lib.az_smallnet_head_floats.restype = C.c_int32
     lib.az_select_wave.argtypes = [vp, vp, C.c_int32, vp]
     lib.az_expand_wave.argtypes = [vp, vp, vp, vp, vp]

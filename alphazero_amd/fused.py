@@ -7,9 +7,10 @@ here; the heads' Linear layers run as one more small MFMA kernel (az_heads_forwa
 weights change (load_state_dict / weight publish).
 
 The reference's QuickModel family (nn_models/quick_model.py with config/quick_model_config.py's default layout, any depth:
-alphazero_amd.nets.QuickNet) is evaluated by the float32 tower only (precision="f32": az_quick_tower_forward_f32 +
-az_quick_heads_forward_f32) -- blocks of ``layers`` x (conv3x3, BN, ReLU) summed with their input after the last ReLU,
-3x3 head convs, two Linear layers per head."""
+alphazero_amd.nets.QuickNet) -- blocks of ``layers`` x (conv3x3, BN, ReLU) summed with their input after the last ReLU,
+3x3 head convs, two Linear layers per head -- runs on the QuickModel instantiations of the same two towers: precision="f32"
+(az_quick_tower_forward_f32 + az_quick_heads_forward_f32, the reference's arithmetic) or "bf16" (az_quick_tower_forward +
+az_quick_heads_forward, throughput mode)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -102,7 +103,7 @@ class FusedTowerEvaluator:
                 isinstance(vh[3], nn.Flatten) and lin(vh[4], n2, 64) and isinstance(vh[5], nn.ReLU) and lin(vh[6], 64, 1)
             # (the family's tanh lives in the module's value_head method, nn_models/quick_model.py:102-104, not in the Sequential:
             # the kernel applies it)
-            ok = ok and (ch == 64 or (ch == 128 and board == 15)) and len(blocks) * layers <= 40
+            ok = ok and ch in (64, 128)
             return (board, ch, len(blocks), layers) if ok else None
         except Exception:
             return None
@@ -136,7 +137,10 @@ class FusedTowerEvaluator:
             return None
         q = FusedTowerEvaluator.quick_shape(model)
         if q is not None:
-            return "f32" if dtype == torch.float32 else None
+            board, ch, nb, nl = q
+            if dtype == torch.float32:  # the f32 tower: 64 channels, or 128 on 15x15; at most 40 conv layers after the transition conv
+                return "f32" if (ch == 64 or board == 15) and nb * nl <= 40 else None
+            return "bf16" if dtype == torch.bfloat16 else None
         if dtype == torch.bfloat16:
             return "bf16"
         if dtype != torch.float32:
@@ -159,11 +163,11 @@ class FusedTowerEvaluator:
             raise EngineError("FusedTowerEvaluator: precision must be 'bf16' or 'f32'")
         self.quick = self.quick_shape(model)
         if self.quick is not None:
-            if precision != "f32":
-                raise EngineError("FusedTowerEvaluator: QuickModel-family networks run on the float32 tower (precision='f32')")
             self.board, self.ch, self.q_blocks, self.q_layers = self.quick
             self.n2 = self.board * self.board
-            self.precision, self.in_dtype = "f32", torch.float32
+            self.precision, self.in_dtype = precision, (torch.float32 if precision == "f32" else torch.bfloat16)
+            if self.precision_for(model, self.in_dtype) is None:
+                raise EngineError("FusedTowerEvaluator: the f32 QuickModel tower takes 64 channels (or 128 on 15x15) and at most 40 conv layers")
             self._buf = {}
             self.kernel_events = None
             self.refresh()
@@ -183,14 +187,16 @@ class FusedTowerEvaluator:
     def _refresh_quick(self) -> None:
         m, dev, n2 = self.model, self.device, self.n2
         sl = list(m._shared_layers)
+        f32 = self.precision == "f32"
+        pack3, packl = (_pack3x3_f32, _pack_linear_f32) if f32 else (_pack3x3, _pack_linear)
         w, b = _fold(sl[0], sl[1])
-        self.w0 = _pack3x3_f32(w, 16).to(dev)
+        self.w0 = pack3(w, 16).to(dev)
         biases, wl = [b], []
         for blk in sl[3:]:
             seq = list(blk.model)
             for i in range(self.q_layers):
                 w, b = _fold(seq[3 * i], seq[3 * i + 1])
-                wl.append(_pack3x3_f32(w, self.ch))
+                wl.append(pack3(w, self.ch))
                 biases.append(b)
         self.n_layers = len(wl)
         self.wl = torch.stack(wl).to(dev).contiguous()
@@ -205,18 +211,18 @@ class FusedTowerEvaluator:
         self.kpq, self.kvq = (2 * n2 + 15) // 16 * 16, (n2 + 15) // 16 * 16
         self.feat_stride = int(self.lib.az_heads_feat_stride(self.board))
         assert self.feat_stride == self.kpq + self.kvq
-        self.w1p = _pack_linear_f32(f(ph[4].weight), 64, self.kpq).to(dev)
+        self.w1p = packl(f(ph[4].weight), 64, self.kpq).to(dev)
         self.b1p = f(ph[4].bias)
-        self.w2p = _pack_linear_f32(f(ph[6].weight), (n2 + 31) // 32 * 32, 64).to(dev)
+        self.w2p = packl(f(ph[6].weight), (n2 + 31) // 32 * 32, 64).to(dev)
         self.b2p = f(ph[6].bias)
-        self.w1v = _pack_linear_f32(f(vh[4].weight), 64, self.kvq).to(dev)
+        self.w1v = packl(f(vh[4].weight), 64, self.kvq).to(dev)
         self.b1v = f(vh[4].bias)
         self.w2v = f(vh[6].weight).reshape(-1)
         self.b2v = float(vh[6].bias.detach().float().reshape(-1)[0])
-        self.stash_bytes = int(self.lib.az_quick_stash_bytes(self.board, self.ch))
-        if self.stash_bytes <= 0:
-            raise EngineError("az_quick_stash_bytes: unsupported board / width")
-        if getattr(self, "stash", None) is None:  # block inputs in flight: one private region per workgroup of a full grid
+        if f32 and getattr(self, "stash", None) is None:  # block inputs in flight: one private region per workgroup of a full grid
+            self.stash_bytes = int(self.lib.az_quick_stash_bytes(self.board, self.ch))
+            if self.stash_bytes <= 0:
+                raise EngineError("az_quick_stash_bytes: unsupported board / width")
             self.stash = torch.empty(self.stash_bytes // 4, dtype=torch.float32, device=dev)
 
     @torch.no_grad()
@@ -296,18 +302,24 @@ class FusedTowerEvaluator:
         if self.quick is not None:
             if list_p is not None:
                 raise EngineError("the f32 tower takes the packed batch with flags (or all slots), not a compact list")
-            rc = self.lib.az_quick_tower_forward_f32(self.board, self.ch, B, self.q_blocks, self.q_layers, P(x) if x is not None else None,
+            if self.precision == "f32":
+                rc = self.lib.az_quick_tower_forward_f32(self.board, self.ch, B, self.q_blocks, self.q_layers, P(x) if x is not None else None,
+                                                         ring_p, leaf_p, flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.headw),
+                                                         P(self.headb), P(feat), self.feat_stride, P(self.stash), self.stash_bytes, st)
+            else:
+                rc = self.lib.az_quick_tower_forward(self.board, self.ch, B, self.q_blocks, self.q_layers, P(x) if x is not None else None,
                                                      ring_p, leaf_p, flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.headw),
-                                                     P(self.headb), P(feat), self.feat_stride, P(self.stash), self.stash_bytes, st)
+                                                     P(self.headb), P(feat), self.feat_stride, st)
             if rc != 0:
-                raise EngineError(f"az_quick_tower_forward_f32 failed ({rc}): {self.lib.az_tower_last_error().decode()}")
+                raise EngineError(f"az_quick_tower_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
             if self.kernel_events is not None:
                 ev1.record()
                 self.kernel_events.append((ev0, ev1))
-            rc = self.lib.az_quick_heads_forward_f32(self.board, B, P(feat), self.feat_stride, P(self.w1p), P(self.b1p), P(self.w2p),
-                                                     P(self.b2p), P(self.w1v), P(self.b1v), P(self.w2v), self.b2v, P(logits), P(value), st)
+            heads = self.lib.az_quick_heads_forward_f32 if self.precision == "f32" else self.lib.az_quick_heads_forward
+            rc = heads(self.board, B, P(feat), self.feat_stride, P(self.w1p), P(self.b1p), P(self.w2p), P(self.b2p), P(self.w1v), P(self.b1v),
+                       P(self.w2v), self.b2v, P(logits), P(value), st)
             if rc != 0:
-                raise EngineError(f"az_quick_heads_forward_f32 failed ({rc}): {self.lib.az_tower_last_error().decode()}")
+                raise EngineError(f"az_quick_heads_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
             return logits, value.view(B, 1)
         if self.precision == "f32":
             if list_p is not None:

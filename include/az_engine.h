@@ -302,6 +302,23 @@ int az_quick_heads_forward_f32(int32_t board_size, int32_t n_boards, const float
                                const float *b1p_dev, const void *w2p_dev, const float *b2p_dev, const void *w1v_dev,
                                const float *b1v_dev, const float *w2v_dev, float b2v, float *logits_dev, float *values_dev, void *stream);
 
+/* The QuickModel family in bf16 throughput mode (bf16 operands and activations, f32 accumulation; NOT the reference's
+ * precision): the bf16 tower kernel of az_tower_forward in its QuickModel instantiation and the heads' Linear layers.  Arguments
+ * as for az_quick_tower_forward_f32 / az_quick_heads_forward_f32 with bf16 tensors packed as for az_tower_forward /
+ * az_heads_forward: x_bf16_dev (n_boards, 9, N, N) bf16 or NULL (packed leaf batch; flags_dev or NULL; no list mode),
+ * w0_dev [9][1][2][C][8], wl_dev [n_blocks * block_layers][9][C/16][2][C][8] bf16, bias_dev [1 + n_blocks * block_layers][C] f32,
+ * headw_dev [3][9 taps][C] f32, headb_dev [3] f32; feat_bf16_dev (n_boards, feat_stride) bf16, row layout as the f32 call's;
+ * the block's input stays in registers (no stash), any depth; channels 64 or 128, board 9 or 15.
+ * az_quick_heads_forward: w1p_dev [2][KPQ/16][2][32][8], w2p_dev [ceil(N*N/32)][4][2][32][8], w1v_dev [2][KVQ/16][2][32][8] bf16;
+ * biases and w2v f32. */
+int az_quick_tower_forward(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_blocks, int32_t block_layers,
+                           const void *x_bf16_dev, const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev,
+                           const void *w0_dev, const void *wl_dev, const float *bias_dev, const float *headw_dev, const float *headb_dev,
+                           void *feat_bf16_dev, int32_t feat_stride, void *stream);
+int az_quick_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16_dev, int32_t feat_stride, const void *w1p_dev,
+                           const float *b1p_dev, const void *w2p_dev, const float *b2p_dev, const void *w1v_dev, const float *b1v_dev,
+                           const float *w2v_dev, float b2v, float *logits_dev, float *values_dev, void *stream);
+
 /* The reference's two small example networks, one launch per evaluation, float32 on v_mfma_f32_16x16x4_f32 (the
  * reference's precision): examples/tictactoe/model.py (game AZ_GAME_TICTACTOE, input (B,9,3,3), 9 logits) and
  * examples/dots_and_boxes/model.py (game AZ_GAME_DAB, input (B,25,4,4), 24 logits); contract nn_models/base.py:17-19

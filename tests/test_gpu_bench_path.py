@@ -98,7 +98,7 @@ def _tower_callback(ev, shape, dtype):
     return O.EVAL_FN(_cb), calls
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f32", "f32-quick"])
+@pytest.mark.parametrize("precision", ["bf16", "f32", "f32-quick", "bf16-quick"])
 def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     """engine + tower on the packed/flags path == oracle + the same tower as its evaluator ("f32-quick": the reference's
     QuickModel family, 128 channels, on the f32 tower's QuickModel instantiation -- config 5's network)"""
@@ -109,8 +109,8 @@ def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     n, G, sims = 15, 64, 100
     rng = np.random.default_rng(5)
     torch.manual_seed(3)
-    dtype = torch.bfloat16 if precision == "bf16" else torch.float32
-    net = _randomised(QuickNet(n, 9, 128, 2, 3) if precision == "f32-quick" else GomokuNet(n, 64, 2)).eval().cuda().to(dtype)
+    dtype = torch.bfloat16 if precision.startswith("bf16") else torch.float32
+    net = _randomised(QuickNet(n, 9, 128, 2, 3) if precision.endswith("quick") else GomokuNet(n, 64, 2)).eval().cuda().to(dtype)
     eng = Engine(2, G, sims, board_size=n, nn_dtype=dtype, device="cuda:0")
     A = eng.dims.n_action
     pos = _positions(oracle, G, rng, n)

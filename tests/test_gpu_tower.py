@@ -328,24 +328,64 @@ def test_quick_tower_rejects_what_it_does_not_implement():
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import QuickNet
 
-    assert FusedTowerEvaluator.quick_shape(QuickNet(15, 9, 96, 1, 5)) is None       # width
-    assert FusedTowerEvaluator.quick_shape(QuickNet(9, 9, 128, 1, 5)) is None        # 128 channels exist for 15x15
-    assert FusedTowerEvaluator.quick_shape(QuickNet(3, 9, 64, 1, 5)) is None         # the reference's own tic-tac-toe instance
-    assert FusedTowerEvaluator.quick_shape(QuickNet(15, 9, 64, 9, 5)) is None        # 45 conv layers
-    assert FusedTowerEvaluator.quick_shape(QuickNet(15, 9, 64, 2, 5, features=32)) is None
+    F = FusedTowerEvaluator
+    assert F.quick_shape(QuickNet(15, 9, 96, 1, 5)) is None       # width
+    assert F.quick_shape(QuickNet(3, 9, 64, 1, 5)) is None         # the reference's own tic-tac-toe instance
+    assert F.quick_shape(QuickNet(15, 9, 64, 2, 5, features=32)) is None
+    assert F.precision_for(QuickNet(9, 9, 128, 1, 5), torch.float32) is None     # f32: 128 channels exist for 15x15
+    assert F.precision_for(QuickNet(9, 9, 128, 1, 5), torch.bfloat16) == "bf16"
+    assert F.precision_for(QuickNet(15, 9, 64, 9, 5), torch.float32) is None     # f32: 45 conv layers
+    assert F.precision_for(QuickNet(15, 9, 64, 9, 5), torch.bfloat16) == "bf16"
+    assert F.precision_for(QuickNet(15, 9, 128, 4, 5), torch.float32) == "f32"
+    assert F.precision_for(QuickNet(15, 9, 128, 4, 5), torch.float16) is None
     with pytest.raises(EngineError):
-        FusedTowerEvaluator(QuickNet(15, 9, 64, 1, 2).eval().cuda(), "bf16")
+        F(QuickNet(9, 9, 128, 1, 2).eval().cuda(), "f32")
 
 
+@pytest.mark.parametrize("board,ch,blocks,layers,batch", [(15, 128, 1, 5, 300), (15, 128, 4, 5, 270), (15, 64, 2, 3, 1100), (15, 64, 3, 1, 33),
+                                                          (9, 64, 2, 5, 4200), (9, 128, 1, 2, 100), (9, 64, 1, 2, 7), (15, 64, 9, 5, 20)])
+def test_quick_tower_bf16_matches_fp32_forward(board, ch, blocks, layers, batch):
+    """QuickModel family on the bf16 tower's QuickModel instantiation + az_quick_heads_forward (throughput mode): same bf16-level
+    bar as the GomokuModel family against the fp32 PyTorch forward, and no worse than PyTorch's own bf16 forward."""
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import QuickNet
+
+    torch.manual_seed(0)
+    net = _randomised(QuickNet(board, 9, ch, blocks, layers)).eval().cuda()
+    ev = FusedTowerEvaluator(net, "bf16")
+    x = torch.randint(-1, 2, (batch, 9, board, board), device="cuda").float()
+    x[:, 8] = torch.where(torch.rand(batch, 1, 1, device="cuda") < 0.5, -1.0, 1.0)
+    with torch.inference_mode():
+        ref_p, ref_v = net(x)
+    p, v = ev(x.bfloat16().contiguous())
+    assert p.shape == ref_p.shape and v.shape == ref_v.shape and p.dtype == torch.float32
+    netb = QuickNet(board, 9, ch, blocks, layers)
+    netb.load_state_dict(net.state_dict())
+    netb = netb.eval().cuda().bfloat16()
+    with torch.inference_mode():
+        bp, bv = netb(x.bfloat16())
+    scale = float(ref_p.abs().max())
+    depth = 1 + blocks * layers
+    err, err_torch = float((p - ref_p).abs().mean()), float((bp.float() - ref_p).abs().mean())
+    assert err <= 1.5 * err_torch + 1e-4, (err, err_torch)
+    assert float((p - ref_p).abs().max()) <= (0.03 + 0.004 * depth) * scale + 0.02, (float((p - ref_p).abs().max()), scale)
+    assert float((v - ref_v).abs().max()) <= max(0.03, 2.0 * float((bv.float() - ref_v).abs().max()))
+    p1, v1 = p.clone(), v.clone()
+    perm = torch.randperm(batch, device="cuda")
+    p2, v2 = ev(x[perm].bfloat16().contiguous())
+    assert torch.equal(p2, p1[perm]) and torch.equal(v2, v1[perm])
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
 @pytest.mark.parametrize("n,ch,blocks,layers,G", [(15, 128, 1, 3, 1100), (15, 64, 2, 2, 2100), (9, 64, 1, 5, 5300)])
-def test_quick_tower_packed_flags_equals_dense(n, ch, blocks, layers, G):
+def test_quick_tower_packed_flags_equals_dense(n, ch, blocks, layers, G, precision):
     """QuickModel instantiation of the f32 tower on the engine's packed leaf batch with every kind of flag pattern (several
     tickets per workgroup, look-ahead of the next board under the running one) == the dense route, row by row"""
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import QuickNet
 
     torch.manual_seed(12)
-    ev = FusedTowerEvaluator(_randomised(QuickNet(n, 9, ch, blocks, layers)).eval().cuda(), "f32")
+    ev = FusedTowerEvaluator(_randomised(QuickNet(n, 9, ch, blocks, layers)).eval().cuda(), precision)
     gen = torch.Generator().manual_seed(6)
     stones = torch.randint(-1, 2, (G, 8, n * n), generator=gen)
     player = torch.randint(0, 2, (G,), generator=gen) * 2 - 1
@@ -359,7 +399,7 @@ def test_quick_tower_packed_flags_equals_dense(n, ch, blocks, layers, G):
     leaf = torch.zeros(G, 4, dtype=torch.int32)
     leaf[:, 3] = player.int()
     leaf = leaf.cuda()
-    x = torch.cat([stones.view(G, 8, n, n).float(), player.view(G, 1, 1, 1).float().expand(G, 1, n, n)], 1).cuda().contiguous()
+    x = torch.cat([stones.view(G, 8, n, n).float(), player.view(G, 1, 1, 1).float().expand(G, 1, n, n)], 1).cuda().to(ev.in_dtype).contiguous()
     pd, vd = ev(x)
     pd, vd = pd.clone(), vd.clone().view(-1)
     patterns = {
