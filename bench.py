@@ -48,7 +48,7 @@ WORKLOADS = {
     "gomoku15_deep64": (2, 15, 800, 16384, dict(board_size=15, channels=64, blocks=10)),
     # configs[4] as written -- "quick_model scaled up": the reference's QuickModel (nn_models/quick_model.py; nets.QuickNet) on the
     # 15x15 board with its default 128 channels and 5-layer residual blocks, RESNET_BLOCK_NUM 1 -> 4: 21 conv layers like
-    # gomoku15_deep, plus the 3x3 head convs; f32 on the tower kernel's QuickModel instantiation
+    # gomoku15_deep, plus the 3x3 head convs; on the tower kernels' QuickModel instantiations (f32 primary, bf16 throughput mode)
     "gomoku15_quick": (2, 15, 800, 16384, dict(board_size=15, channels=128, blocks=4, layers=5)),
     "dab": (1, 3, 80, 3000, {}),
     "tictactoe": (0, 3, 50, 1000, {}),
@@ -424,7 +424,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
                    "flops_per_eval": flops_per_eval, "boards_per_batch": evals_per_launch,
                    "share_of_step": nn_ms / max(nn_ms + tree_ms, 1e-9),
                    "implementation": (("az_smallnet.hip: k_smallnet_f32 (the whole network, one f32 MFMA kernel)" if game != 2 else
-                                       "az_tower_f32.hip: k_tower_f32_t16<QuickModel> (f32 MFMA conv tower, 16-cell tiles, 3x3 head convs) + k_quick_heads_f32"
+                                       ("az_tower_f32.hip: k_tower_f32_t16<QuickModel> (f32 MFMA conv tower, 16-cell tiles, 3x3 head convs) + k_quick_heads_f32"
+                                        if dtype_name == "f32" else "az_tower.hip: k_tower<QuickModel> (fused bf16 MFMA conv tower, 3x3 head convs) + k_quick_heads")
                                        if "layers" in WORKLOADS[args.workload][4] else
                                        "az_tower_f32.hip: k_tower_f32_t16 (f32 MFMA conv tower, 16-cell tiles) + k_heads_f32" if dtype_name == "f32" else
                                        "az_tower.hip: k_tower (fused bf16 MFMA conv tower) + k_heads (MFMA head linears)")
@@ -618,8 +619,7 @@ def main():
     out = measure(args, primary, args.steps, args.warmup, dev, rank, world, use_dist)
     sec_steps = args.secondary_steps if args.secondary_steps >= 0 else (min(args.steps, 4) if world == 1 else 0)
     second = None
-    if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1 \
-            and "layers" not in kw:  # (the QuickModel family has no bf16 tower)
+    if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1:
         second = measure(args, "bf16", sec_steps, 1, dev, rank, world, use_dist)
     if rank == 0:
         out["cpu_baseline"] = cpu
