@@ -282,6 +282,19 @@ class Engine:
         self._ck(self.lib.az_leaf_buffers(self._h, C.byref(ring), C.byref(leaf), C.byref(lst), C.byref(cnt), C.byref(flg)))
         return ring.value, leaf.value, lst.value, cnt.value, flg.value
 
+    def leaf_flags(self) -> torch.Tensor:
+        """the per-row needs-the-network flags of the last select_gather as a uint8 tensor (rows,) that ALIASES the engine's
+        buffer (zero copy, through __cuda_array_interface__): 1 = the row's leaf wants an evaluation, 0 = terminal / inactive"""
+        if getattr(self, "_flags_view", None) is None:
+            ptr, rows = self.leaf_buffers()[4], self.rows
+
+            class _Dev:
+                __cuda_array_interface__ = {"shape": (rows,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+            with torch.cuda.device(self.device):
+                self._flags_view = torch.as_tensor(_Dev(), device=self.device)
+        return self._flags_view
+
     def compact_leaves(self):
         """fill the list/count of leaf_buffers() for the batch of the last select_gather"""
         self._ck(self.lib.az_compact_leaves(self._h, self._stream()))

@@ -21,9 +21,12 @@ from .engine import Engine, EngineError
 @torch.no_grad()
 def play_match(game_cls, model_a: torch.nn.Module, model_b: torch.nn.Module, n_games: int,
                num_simulation: int = TRAIN_NUM_SIMULATION, c_puct: float = C_PUCT,
-               device: Optional[torch.device] = None, record_moves: bool = False) -> dict:
+               device: Optional[torch.device] = None, record_moves: bool = False, fused: Optional[bool] = False) -> dict:
     """Returns {"a_wins", "b_wins", "draws", "results" (n_games,) from A's point of view in {+1, 0, -1},
-    "plies" (n_games,), and with record_moves "moves": a list of (n_games,) int32 tensors, -1 once a game is over}."""
+    "plies" (n_games,), and with record_moves "moves": a list of (n_games,) int32 tensors, -1 once a game is over}.
+    ``fused``: False = each network's own PyTorch forward on the rows it owns; True / None = the hand-written f32 network
+    kernels (alphazero_amd.fused) reading the packed leaf batch, each network evaluating the rows flagged for it (None: only
+    when kernels cover BOTH networks; True: required)."""
     if not torch.cuda.is_available():
         raise EngineError("play_match needs a GPU (no CPU fallback)")
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -32,7 +35,19 @@ def play_match(game_cls, model_a: torch.nn.Module, model_b: torch.nn.Module, n_g
     d = eng.dims
     A = d.n_action
     models = (model_a.to(dev).eval(), model_b.to(dev).eval())
-    nn = eng.new_nn_input()
+    evs = None
+    if fused is None or fused:
+        from .fused import FusedTowerEvaluator, SmallNetEvaluator, evaluator_available
+
+        ok = all(evaluator_available(game_id, m, torch.float32) for m in models)
+        if fused and not ok:
+            raise EngineError("play_match(fused=True): no hand-written f32 kernel covers both networks")
+        if ok:
+            evs = tuple(FusedTowerEvaluator(m, "f32") if game_id == 2 else SmallNetEvaluator(m) for m in models)
+            ring, leaf, _, _, _ = eng.leaf_buffers()
+            flags = eng.leaf_flags()
+            own_logits = (eng.new(n_games, A), eng.new(n_games, A))
+    nn = eng.new_nn_input() if evs is None else None
     logits, values = eng.new(n_games, A), eng.new(n_games)
     actions = eng.new(n_games, dtype=torch.int32)
     done = torch.zeros(n_games, dtype=torch.uint8, device=dev)
@@ -53,6 +68,18 @@ def play_match(game_cls, model_a: torch.nn.Module, model_b: torch.nn.Module, n_g
         eng.begin_search()
         for _ in range(num_simulation):
             eng.select_gather(nn)
+            if evs is not None:
+                # each network evaluates the rows that are its own AND need the network (its flag bytes); rows of the other
+                # network keep stale data in this evaluator's outputs and are taken from the other's
+                vs = []
+                for k, ev in enumerate(evs):
+                    fl = flags & (a_to_move if k == 0 else ~a_to_move).to(torch.uint8)
+                    _, v = ev(None, logits_out=own_logits[k], packed=(ring, leaf, None, None, fl.data_ptr()), n_boards=n_games)
+                    vs.append(v.view(-1))
+                torch.where(a_to_move.view(-1, 1), own_logits[0], own_logits[1], out=logits)
+                torch.where(a_to_move, vs[0], vs[1], out=values)
+                eng.expand_backup(logits, values, None)
+                continue
             for m, ix in zip(models, idx):
                 if ix.numel():
                     p, v = m(nn.index_select(0, ix).to(next(m.parameters()).dtype))
