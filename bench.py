@@ -563,7 +563,8 @@ def main():
     ap.add_argument("--evaluator", default="auto", choices=["auto", "fused", "model", "hash"],
                     help="fused = hand-written MFMA conv tower (az_tower.hip / az_tower_f32.hip); model = the module's own PyTorch forward; "
                          "auto = fused when the network is a GomokuModel-family tower the kernels cover")
-    ap.add_argument("--graph", type=int, default=0, help="1: the timed steps replay the simulation step as a captured HIP graph "
+    ap.add_argument("--graph", type=int, default=-1, help="-1 (default): 1 for the workloads whose configuration has at most 4,096 games (gomoku9, dab, tictactoe), 0 otherwise.  "
+                    "1: the timed steps replay the simulation step as a captured HIP graph "
                     "(what the small, launch-bound games want); the per-kernel HIP-event times then come from one eager probe "
                     "step run after the timed region.  0 (default): eager launches, events inside the timed region")
     ap.add_argument("--leaves", type=int, default=1, help="leaves per tree per network batch: > 1 = virtual loss / in-tree leaf "
@@ -577,6 +578,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the "
                     "barrier / all-reduce / weight-broadcast path on a one-GPU box")
     args = ap.parse_args()
+    if args.graph < 0:
+        args.graph = 1 if WORKLOADS[args.workload][3] <= 4096 and args.leaves <= 1 and args.evaluator != "hash" else 0
 
     # a line on stderr every 45 s: the deep configurations run minutes between two outputs, and a harness that watches for
     # silence would take them for hung
