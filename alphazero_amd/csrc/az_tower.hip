@@ -6,7 +6,9 @@
 // activations resident in LDS for the whole tower and every conv an implicit GEMM on bf16 MFMA
 // (v_mfma_f32_32x32x16_bf16, f32 accumulate), and the heads' Linear layers in a second small kernel (k_heads).
 // BatchNorm (eval mode) is folded into the conv weights and a per-channel bias by the host (alphazero_amd/fused.py).
-// C ABI at the bottom; declared in include/az_engine.h.
+// The same kernel has a QuickModel instantiation (k_tower<.., QK = true>; nn_models/quick_model.py, resnet_blocks.py:28-40:
+// blocks of n x (conv3x3, BN, ReLU) added to their input after the last ReLU, 3x3 head convs) with k_quick_heads for that
+// family's two-layer heads.  C ABI at the bottom; declared in include/az_engine.h.
 //
 // k_tower (one workgroup = 4 waves = BPW boards at a time; persistent, two workgroups per CU):
 //   LDS act[cell][64 ch] bf16, cells packed without halo (cell = board*N*N + row*N + col), 128 B per

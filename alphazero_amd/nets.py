@@ -4,8 +4,8 @@
            = policy_head(shared_layers(x)), value_head(shared_layers(x))
 
 The engine only needs the contract: any reference ``BaseModel`` subclass works unchanged through its own
-PyTorch-ROCm forward; the GomokuNet family (64 or 128 channels) is additionally evaluated by the hand-written
-fused MFMA tower (alphazero_amd.fused / csrc/az_tower.hip).  The nets here exist because the
+PyTorch-ROCm forward; the GomokuNet and QuickNet families (64 or 128 channels) and the two small nets are additionally
+evaluated by the hand-written fused MFMA kernels (alphazero_amd.fused / csrc/az_tower*.hip, csrc/az_smallnet.hip).  The nets here exist because the
 reference does not travel to the GPU box: they rebuild the reference's example architectures
 (examples/tictactoe/model.py, examples/dots_and_boxes/model.py, examples/gomoku/model.py) with the
 SAME parameter names, so a reference checkpoint (result/models/*/last_model.pth) loads with
@@ -134,8 +134,8 @@ class QuickNet(DualHeadNet):
     reference's defaults: transition conv3x3(C_in -> channels)+BN+ReLU, ``blocks`` residual blocks of ``layers`` x
     (conv3x3, BN, ReLU) with the sum taken AFTER the last ReLU; policy head conv3x3(channels -> 2)+BN+ReLU, Linear(2HW -> 64),
     ReLU, Linear(64 -> A); value head conv3x3(channels -> 1)+BN+ReLU, Linear(HW -> 64), ReLU, Linear(64 -> 1), tanh applied
-    in ``value_head`` (:131-133).  It runs through its own PyTorch-ROCm forward (the fused towers cover the GomokuModel
-    family: 1x1 head convs, sum before the last ReLU)."""
+    in ``value_head`` (:131-133).  Evaluated by its own PyTorch-ROCm forward or, at 64 / 128 channels on the 9x9 / 15x15 boards,
+    by the QuickModel instantiations of the fused towers (fused.FusedTowerEvaluator: f32 = the reference's precision, bf16)."""
 
     def __init__(self, board_size: int = 15, in_channels: int = HISTORY_LEN + 1, channels: int = 128, blocks: int = 1,
                  layers: int = 5, n_action: int | None = None, features: int = 64) -> None:

@@ -557,12 +557,12 @@ def main():
     ap.add_argument("--sims", type=int, default=0)
     ap.add_argument("--dtype", default="auto", choices=["auto", "bf16", "f16", "f32"],
                     help="network arithmetic of the PRIMARY line.  auto = f32, the reference's own precision (nn_models/base.py:17-19): the "
-                         "hand-written f32 tower for the GomokuModel family, the module's own PyTorch forward otherwise")
+                         "hand-written f32 kernels for the GomokuModel / QuickModel families and the two small nets, the module's own PyTorch forward otherwise")
     ap.add_argument("--secondary-steps", type=int, default=-1, help="timed steps of the second line at the other precision (bf16 "
                     "throughput mode beside an f32 primary), reported as the object 'throughput_mode'; -1 = min(steps, 4) at one GPU, 0 = skip")
     ap.add_argument("--evaluator", default="auto", choices=["auto", "fused", "model", "hash"],
                     help="fused = hand-written MFMA conv tower (az_tower.hip / az_tower_f32.hip); model = the module's own PyTorch forward; "
-                         "auto = fused when the network is a GomokuModel-family tower the kernels cover")
+                         "auto = fused when a hand-written kernel covers the network at this precision")
     ap.add_argument("--graph", type=int, default=-1, help="-1 (default): 1 for the workloads whose configuration has at most 4,096 games (gomoku9, dab, tictactoe), 0 otherwise.  "
                     "1: the timed steps replay the simulation step as a captured HIP graph "
                     "(what the small, launch-bound games want); the per-kernel HIP-event times then come from one eager probe "
