@@ -1246,8 +1246,8 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
   if ((!x_f32_dev && (!packed_ring_dev || !packed_leaf_dev)) || !w0_dev || !bias_dev || !headw_dev || !headb_dev || !feat_f32_dev ||
       (n_conv_layers > 0 && !wl_dev)) { tower_set_error("null argument"); return AZ_EINVAL; }
   if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1)) { tower_set_error("n_boards >= 1, even n_conv_layers"); return AZ_EINVAL; }
-  if ((board_size != 9 && board_size != 15) || (channels != 64 && !(channels == 128 && board_size == 15))) {
-    tower_set_error("f32 tower: board_size 9 or 15 with 64 channels, or 15 with 128 channels");
+  if ((board_size != 9 && board_size != 15) || (channels != 64 && channels != 128)) {
+    tower_set_error("f32 tower: board_size 9 or 15, 64 or 128 channels");
     return AZ_EINVAL;
   }
   if (channels == 128 && n_conv_layers > T16_MAX_LAYERS) { tower_set_error("f32 tower, 128 channels: at most 40 conv layers"); return AZ_EINVAL; }
@@ -1291,7 +1291,8 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
            (size_t)(1 + T16_MAX_LAYERS) * cw * 4;
   };
   static const bool use32 = getenv("AZ_TOWER_F32_TILE32") != nullptr;  // diagnostic: the 32-cell-tile kernel on 15x15 too
-  if (channels == 128) rc = launch(k_tower_f32_t16<128, 15>, lds_t16(128, 15), 1, 3, 1, 512);
+  if (channels == 128 && board_size == 15) rc = launch(k_tower_f32_t16<128, 15>, lds_t16(128, 15), 1, 3, 1, 512);
+  else if (channels == 128) rc = launch(k_tower_f32_t16<128, 9>, lds_t16(128, 9), 1, 5, 1, 512);  // (8 waves x one 16-channel tile, one workgroup per CU)
   else if (board_size == 15 && !use32 && n_conv_layers <= T16_MAX_LAYERS) rc = launch(k_tower_f32_t16<64, 15>, lds_t16(64, 15), 1, 2);
   else if (board_size == 15) rc = launch(k_tower_f32<15, 1>, GeoF<15, 1>::lds_bytes(), 1, 0);
   else if (!use32 && n_conv_layers <= T16_MAX_LAYERS) rc = launch(k_tower_f32_t16<64, 9>, lds_t16(64, 9), 1, 4, T16Geo<64, 9>::WG_PER_CU);
@@ -1305,6 +1306,7 @@ int az_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards,
 int64_t az_quick_stash_bytes(int32_t board_size, int32_t channels) {
   using namespace aztf32;
   if (board_size == 15 && channels == 128) return (int64_t)256 * 1 * T16Geo<128, 15>::NW * (T16Geo<128, 15>::NT * T16Geo<128, 15>::NCT * 256 + 64) * 4;
+  if (board_size == 9 && channels == 128) return (int64_t)256 * 1 * T16Geo<128, 9>::NW * (T16Geo<128, 9>::NT * T16Geo<128, 9>::NCT * 256 + 64) * 4;
   if (board_size == 15 && channels == 64) return (int64_t)256 * 2 * T16Geo<64, 15>::NW * (T16Geo<64, 15>::NT * T16Geo<64, 15>::NCT * 256 + 64) * 4;
   if (board_size == 9 && channels == 64) return (int64_t)256 * T16Geo<64, 9>::WG_PER_CU * T16Geo<64, 9>::NW * (T16Geo<64, 9>::NT * T16Geo<64, 9>::NCT * 256 + 64) * 4;
   return -1;
@@ -1323,7 +1325,7 @@ int az_quick_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_b
     return AZ_EINVAL;
   }
   const int64_t need = az_quick_stash_bytes(board_size, channels);
-  if (need < 0) { tower_set_error("quick tower: board_size 9 or 15 with 64 channels, or 15 with 128 channels"); return AZ_EINVAL; }
+  if (need < 0) { tower_set_error("quick tower: board_size 9 or 15, 64 or 128 channels"); return AZ_EINVAL; }
   if (stash_bytes < need) { tower_set_error("quick tower: stash_bytes below az_quick_stash_bytes(board_size, channels)"); return AZ_EINVAL; }
   if (feat_stride < az_heads_feat_stride(board_size)) { tower_set_error("feat_stride below az_heads_feat_stride(board_size)"); return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
@@ -1363,7 +1365,8 @@ int az_quick_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_b
     return AZ_OK;
   };
   int rc;
-  if (channels == 128) rc = launch(k_tower_f32_t16<128, 15, true>, lds_t16(128, 15), 8, 1, 512);
+  if (channels == 128 && board_size == 15) rc = launch(k_tower_f32_t16<128, 15, true>, lds_t16(128, 15), 8, 1, 512);
+  else if (channels == 128) rc = launch(k_tower_f32_t16<128, 9, true>, lds_t16(128, 9), 11, 1, 512);
   else if (board_size == 15) rc = launch(k_tower_f32_t16<64, 15, true>, lds_t16(64, 15), 9, 2, 256);
   else rc = launch(k_tower_f32_t16<64, 9, true>, lds_t16(64, 9), 10, T16Geo<64, 9>::WG_PER_CU, 256);
   if (rc != AZ_OK) return rc;

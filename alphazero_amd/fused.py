@@ -131,22 +131,22 @@ class FusedTowerEvaluator:
     @staticmethod
     def precision_for(model: nn.Module, dtype: torch.dtype):
         """"bf16" / "f32" when a hand-written tower evaluates this module at this engine dtype, else None (the module's own
-        PyTorch forward runs): GomokuModel family in bf16 (64 / 128 channels) and f32 (64 channels; 128 on 15x15), QuickModel
-        family in f32"""
+        PyTorch forward runs): GomokuModel family and QuickModel family in bf16 and f32 (64 / 128 channels; f32 QuickModel and
+        128-channel f32 towers up to 40 conv layers)"""
         if not FusedTowerEvaluator.supports(model):
             return None
         q = FusedTowerEvaluator.quick_shape(model)
         if q is not None:
             board, ch, nb, nl = q
-            if dtype == torch.float32:  # the f32 tower: 64 channels, or 128 on 15x15; at most 40 conv layers after the transition conv
-                return "f32" if (ch == 64 or board == 15) and nb * nl <= 40 else None
+            if dtype == torch.float32:  # the f32 tower: at most 40 conv layers after the transition conv
+                return "f32" if nb * nl <= 40 else None
             return "bf16" if dtype == torch.bfloat16 else None
         if dtype == torch.bfloat16:
             return "bf16"
         if dtype != torch.float32:
             return None
-        ch, n2 = model._shared_layers[0].out_channels, model._policy_head[4].in_features
-        return "f32" if ch == 64 or (ch == 128 and n2 == 225) else None
+        ch, n_layers = model._shared_layers[0].out_channels, 2 * (len(model._shared_layers) - 3)
+        return "f32" if ch == 64 or n_layers <= 40 else None  # (128 channels: the 16-cell-tile kernel only, bias table of 40 layers)
 
     def __init__(self, model: nn.Module, precision: str = "bf16"):
         """precision: "bf16" (az_tower.hip: bf16 operands, f32 accumulation -- the throughput mode) or "f32"
@@ -167,7 +167,7 @@ class FusedTowerEvaluator:
             self.n2 = self.board * self.board
             self.precision, self.in_dtype = precision, (torch.float32 if precision == "f32" else torch.bfloat16)
             if self.precision_for(model, self.in_dtype) is None:
-                raise EngineError("FusedTowerEvaluator: the f32 QuickModel tower takes 64 channels (or 128 on 15x15) and at most 40 conv layers")
+                raise EngineError("FusedTowerEvaluator: the f32 QuickModel tower takes at most 40 conv layers after the transition conv")
             self._buf = {}
             self.kernel_events = None
             self.refresh()
@@ -175,8 +175,8 @@ class FusedTowerEvaluator:
         self.n2 = model._policy_head[4].in_features
         self.board = 15 if self.n2 == 225 else 9
         self.ch = model._shared_layers[0].out_channels
-        if precision == "f32" and not (self.ch == 64 or (self.ch == 128 and self.board == 15)):
-            raise EngineError("FusedTowerEvaluator: the f32 tower exists for 64-channel trunks (9x9, 15x15) and 128-channel 15x15 trunks")
+        if precision == "f32" and self.precision_for(model, torch.float32) is None:
+            raise EngineError("FusedTowerEvaluator: the f32 tower takes 128-channel trunks of at most 40 conv layers")
         self.precision = precision
         self.in_dtype = torch.float32 if precision == "f32" else torch.bfloat16
         self._buf = {}

@@ -260,7 +260,8 @@ const char *az_tower_last_error(void);
 
 /* The same two calls at the REFERENCE'S precision: the reference runs its network in float32 (nn_models/base.py:17-19
  * under core/MCTS_alphazero.py:161-162, no autocast).  f32 operands and f32 accumulation on the f32 MFMAs (each output
- * is a k-ordered fmaf chain; dense peak 157.3 TFLOP/s).  64-channel trunks on board 9 or 15, 128-channel trunks on board 15.
+ * is a k-ordered fmaf chain; dense peak 157.3 TFLOP/s).  64- or 128-channel trunks on board 9 or 15 (128 channels: at most 40
+ * conv layers).
  *   x_f32_dev (n_boards, 9, N, N) f32 or NULL to read the packed leaf batch (with flags_dev, only the flagged slots);
  *   w0_dev [9 taps][2][2][C][4] f32, wl_dev [n_conv_layers][9][C/8][2][C][4] f32 ([tap][k-step of 8 ci][k-half][co][4 ci]);
  *   in w0 the 9 input channels sit at positions c + c / 3 of the 16 (0,1,2, 4,5,6, 8,9,10), the other positions are zero;
@@ -291,7 +292,7 @@ int az_heads_forward_f32(int32_t board_size, int32_t n_boards, const float *feat
  *                              value = tanh(relu(feat[:, KPQ:KPQ+N*N] @ W1v^T + b1v) @ w2v + b2v),  KPQ = 2N*N rounded up to 16;
  *   w1p_dev [2][KPQ/8][2][32][4], w2p_dev [ceil(N*N/32)][8][2][32][4], w1v_dev [2][KVQ/8][2][32][4] f32 ([output tile][k-step of
  *   8][k-half][output][4 k], zero padded; KVQ = N*N rounded up to 16); b1p (64), b2p (N*N), b1v (64), w2v (64) f32, b2v.
- * Boards 9 and 15 with 64 channels, board 15 with 128 channels.  Errors through az_tower_last_error(). */
+ * Boards 9 and 15, 64 or 128 channels.  Errors through az_tower_last_error(). */
 int64_t az_quick_stash_bytes(int32_t board_size, int32_t channels);
 int az_quick_tower_forward_f32(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_blocks, int32_t block_layers,
                                const float *x_f32_dev, const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev,

@@ -52,7 +52,7 @@ def test_fused_tower_matches_fp32_forward(board, blocks, batch, ch):
 
 @pytest.mark.parametrize("board,blocks,batch,ch", [(15, 2, 64, 64), (15, 2, 1100, 64), (15, 3, 33, 64), (9, 2, 100, 64), (9, 1, 7, 64),
                                                    (15, 0, 5, 64), (9, 0, 4, 64), (15, 10, 600, 64), (9, 6, 50, 64),
-                                                   (15, 2, 300, 128), (15, 10, 270, 128), (15, 0, 9, 128),
+                                                   (15, 2, 300, 128), (15, 10, 270, 128), (15, 0, 9, 128), (9, 3, 700, 128), (9, 0, 5, 128),
                                                    (9, 2, 4096, 64), (9, 21, 40, 64), (15, 21, 5, 64)])  # (42 conv layers: the 32-cell-tile kernel)
 def test_f32_tower_matches_fp32_forward(board, blocks, batch, ch):
     """az_tower_f32.hip: f32 operands, f32 accumulation -- the reference's own arithmetic (nn_models/base.py:17-19).  Bar
@@ -232,7 +232,8 @@ def test_zero_block_tower_packed_flags_many_tickets(precision, board, G):
     eng.check()
 
 
-@pytest.mark.parametrize("n,ch,blocks,G", [(15, 64, 2, 2100), (15, 64, 0, 2100), (15, 128, 1, 2100), (9, 64, 2, 5300), (9, 64, 0, 5300)])
+@pytest.mark.parametrize("n,ch,blocks,G", [(15, 64, 2, 2100), (15, 64, 0, 2100), (15, 128, 1, 2100), (9, 64, 2, 5300), (9, 64, 0, 5300),
+                                           (9, 128, 1, 1300)])
 def test_f32_tower_lookahead_under_random_flags(n, ch, blocks, G):
     """The f32 tower (16-cell-tile kernel, 15x15 and 9x9) hands boards out by ticket and looks the next board up under the running one (ticket, flag byte and
     packed input by LDS-DMA into a second buffer).  Synthetic packed batches with every kind of flag pattern -- dense, sparse,
@@ -285,7 +286,8 @@ def test_f32_tower_lookahead_under_random_flags(n, ch, blocks, G):
 
 
 @pytest.mark.parametrize("board,ch,blocks,layers,batch", [(15, 128, 1, 5, 300), (15, 128, 4, 5, 270), (15, 64, 2, 3, 1100), (15, 64, 3, 1, 33),
-                                                          (9, 64, 2, 5, 4200), (9, 64, 1, 2, 7), (15, 128, 2, 2, 5), (15, 64, 8, 5, 40)])
+                                                          (9, 64, 2, 5, 4200), (9, 64, 1, 2, 7), (15, 128, 2, 2, 5), (15, 64, 8, 5, 40),
+                                                          (9, 128, 2, 3, 600)])
 def test_quick_tower_matches_fp32_forward(board, ch, blocks, layers, batch):
     """The reference's QuickModel family (nn_models/quick_model.py, resnet_blocks.py:28-40; nets.QuickNet is pinned to the
     reference's own QuickModel by tests/golden/quick.npz) on the f32 tower's QuickModel instantiation + az_quick_heads_forward_f32.
@@ -332,14 +334,14 @@ def test_quick_tower_rejects_what_it_does_not_implement():
     assert F.quick_shape(QuickNet(15, 9, 96, 1, 5)) is None       # width
     assert F.quick_shape(QuickNet(3, 9, 64, 1, 5)) is None         # the reference's own tic-tac-toe instance
     assert F.quick_shape(QuickNet(15, 9, 64, 2, 5, features=32)) is None
-    assert F.precision_for(QuickNet(9, 9, 128, 1, 5), torch.float32) is None     # f32: 128 channels exist for 15x15
+    assert F.precision_for(QuickNet(9, 9, 128, 1, 5), torch.float32) == "f32"
     assert F.precision_for(QuickNet(9, 9, 128, 1, 5), torch.bfloat16) == "bf16"
     assert F.precision_for(QuickNet(15, 9, 64, 9, 5), torch.float32) is None     # f32: 45 conv layers
     assert F.precision_for(QuickNet(15, 9, 64, 9, 5), torch.bfloat16) == "bf16"
     assert F.precision_for(QuickNet(15, 9, 128, 4, 5), torch.float32) == "f32"
     assert F.precision_for(QuickNet(15, 9, 128, 4, 5), torch.float16) is None
     with pytest.raises(EngineError):
-        F(QuickNet(9, 9, 128, 1, 2).eval().cuda(), "f32")
+        F(QuickNet(15, 9, 64, 9, 5).eval().cuda(), "f32")
 
 
 @pytest.mark.parametrize("board,ch,blocks,layers,batch", [(15, 128, 1, 5, 300), (15, 128, 4, 5, 270), (15, 64, 2, 3, 1100), (15, 64, 3, 1, 33),
