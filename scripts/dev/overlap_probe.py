@@ -9,11 +9,12 @@ from alphazero_amd.nets import GomokuNet
 torch.manual_seed(0)
 dev = torch.device("cuda", 0)
 sims = int(os.environ.get("SIMS", "200"))
+DT = torch.float32 if os.environ.get("DTYPE", "bf16") == "f32" else torch.bfloat16
 model = None  # built in __main__ (nothing touches the GPU at import)
 
 
 def make(slots, graph):
-    eng = Engine(2, slots, sims, board_size=15, nn_dtype=torch.bfloat16, device=dev)
+    eng = Engine(2, slots, sims, board_size=15, nn_dtype=DT, device=dev)
     run = SelfPlayRunner(eng, model, sims, fused=True, use_graph=graph)
     return eng, run
 
@@ -57,6 +58,6 @@ def bench(parts, graph, moves=3):
 
 
 if __name__ == "__main__":
-    model = GomokuNet(15, 64, 2).eval().to(dev).to(torch.bfloat16)
-    for parts, graph in ((1, False), (2, False), (2, True)):
+    model = GomokuNet(15, 64, 2).eval().to(dev).to(DT)
+    for parts, graph in ((1, False), (2, False), (4, False)):
         bench(parts, graph)
