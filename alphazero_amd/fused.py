@@ -348,8 +348,8 @@ class FusedTowerEvaluator:
         """The same evaluation through az_tower_heads_forward_static: nothing is allocated -- not here (the caller owns
         ``logits`` (B, N*N) and ``values`` (B,) f32) and not in the library (the feature rows between the two kernels live
         in its static per-GPU array).  B is limited to ``az_static_max_boards``; calls on one GPU must not overlap."""
-        if self.precision != "bf16":
-            raise EngineError("forward_static exists for the bf16 tower")
+        if self.precision != "bf16" or self.quick is not None:
+            raise EngineError("forward_static exists for the bf16 tower of the GomokuModel family")
         if x is not None:
             if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.device != self.device or x.shape[1] != 9:
                 raise EngineError("forward_static expects a contiguous (B,9,N,N) bf16 batch on the model's GPU")
