@@ -133,21 +133,23 @@ def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     assert calls[0] == eng.read_stats()["evals"]
 
 
-def test_runner_search_graph_replay_matches_eager(oracle):
+@pytest.mark.parametrize("kind", ["gomokunet-bf16", "quicknet-f32", "quicknet-bf16"])
+def test_runner_search_graph_replay_matches_eager(oracle, kind):
     """the HIP-graph replay of the simulation step (what the small configs run) == the eager loop, bit for bit"""
     from alphazero_amd import Engine
     from alphazero_amd.arena import SelfPlayRunner
-    from alphazero_amd.nets import GomokuNet
+    from alphazero_amd.nets import GomokuNet, QuickNet
 
     n, G, sims = 9, 48, 60
     rng = np.random.default_rng(9)
     torch.manual_seed(4)
-    net = _randomised(GomokuNet(n, 64, 2)).eval().cuda().bfloat16()
+    dt = torch.float32 if kind.endswith("f32") else torch.bfloat16
+    net = _randomised(QuickNet(n, 9, 64, 2, 2) if kind.startswith("quick") else GomokuNet(n, 64, 2)).eval().cuda().to(dt)
     pos = _positions(oracle, G, rng, n, 20)
     noise_np = rng.dirichlet([0.3] * (n * n), size=G).astype(np.float32)
     out = []
     for graph in (False, True):
-        eng = Engine(2, G, sims, board_size=n, nn_dtype=torch.bfloat16, device="cuda:0")
+        eng = Engine(2, G, sims, board_size=n, nn_dtype=dt, device="cuda:0")
         for g, (h, p) in enumerate(pos):
             eng.set_position(g, h, p)
         run = SelfPlayRunner(eng, net, sims, fused=True, use_graph=graph)
