@@ -639,6 +639,7 @@ def main():
             out["throughput_mode"] = second
         print(json.dumps(out))
     if use_dist:
+        dist.barrier()  # rank 0 arrives last (game-length probe, printing): every rank leaves the group together
         dist.destroy_process_group()
 
 
