@@ -407,7 +407,8 @@ def test_bulk_writer_fills_the_reference_ring_like_its_own_puts(name, game, n, A
     assert torch.equal(got._states, want._states) and torch.equal(got._prior, want._prior) and torch.equal(got._values, want._values)
 
 
-@pytest.mark.parametrize("kind", ["gomokunet-128x4-fused-bf16", "quicknet-128x2x3-fused-f32", "quicknet-128x2x3-pytorch-f32"])
+@pytest.mark.parametrize("kind", ["gomokunet-128x4-fused-bf16", "quicknet-128x2x3-fused-f32", "quicknet-128x2x3-fused-bf16",
+                                  "quicknet-128x2x3-pytorch-f32"])
 def test_config5_shape_self_play_train_loop(kind):
     """BASELINE config 5 at its real board and width (gomoku 15x15, 128 channels, >= 4 residual conv pairs), a few moves of
     the self-play + training loop: the GomokuNet-family tower on the fused bf16 kernel, and the reference's QuickModel
@@ -420,7 +421,7 @@ def test_config5_shape_self_play_train_loop(kind):
     if kind.startswith("gomokunet"):
         net, dt = GomokuNet(15, 128, 4), torch.bfloat16
     else:
-        net, dt = QuickNet(15, 9, 128, 2, 3), torch.float32
+        net, dt = QuickNet(15, 9, 128, 2, 3), (torch.bfloat16 if kind.endswith("bf16") else torch.float32)
     loop = SelfPlayTrainLoop(net, 2, 15, 48, 12, torch.device("cuda:0"), ring_capacity=1 << 13, batch_size=64,
                              train_steps_per_move=1, min_samples=256, publish_every=2, nn_dtype=dt,
                              fused=False if "pytorch" in kind else None)
