@@ -221,6 +221,7 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
+            self._flags_view = None  # (aliases engine memory: the caller must not use a view obtained earlier after close())
             self.lib.az_destroy(self._h)
             self._h = None
 
@@ -284,7 +285,8 @@ class Engine:
 
     def leaf_flags(self) -> torch.Tensor:
         """the per-row needs-the-network flags of the last select_gather as a uint8 tensor (rows,) that ALIASES the engine's
-        buffer (zero copy, through __cuda_array_interface__): 1 = the row's leaf wants an evaluation, 0 = terminal / inactive"""
+        buffer (zero copy, through __cuda_array_interface__): 1 = the row's leaf wants an evaluation, 0 = terminal / inactive.
+        Valid until close()."""
         if getattr(self, "_flags_view", None) is None:
             ptr, rows = self.leaf_buffers()[4], self.rows
 
