@@ -380,3 +380,26 @@ def test_quicknet_is_the_reference_quickmodel():
     big = nets.QuickNet(15, 9, 128, 4, 5)  # "scaled up" for gomoku 15x15 (BASELINE config 5)
     p, v = big.eval()(torch.zeros(2, 9, 15, 15))
     assert p.shape == (2, 225) and v.shape == (2, 1)
+
+
+def test_fused_kernel_selection_is_decided_from_the_module_alone():
+    """Which hand-written network kernel (if any) serves a module at an engine dtype -- the decision ChessArena(fused=None),
+    SelfPlayTrainLoop and bench.py make -- needs no GPU: it reads the module's layer sequence."""
+    import torch
+
+    from alphazero_amd import nets
+    from alphazero_amd.fused import FusedTowerEvaluator as F, SmallNetEvaluator as S, evaluator_available
+
+    f32, bf16, f16 = torch.float32, torch.bfloat16, torch.float16
+    assert F.precision_for(nets.GomokuNet(15, 64, 2), f32) == "f32" and F.precision_for(nets.GomokuNet(15, 64, 2), bf16) == "bf16"
+    assert F.precision_for(nets.GomokuNet(9, 128, 3), f32) == "f32" and F.precision_for(nets.GomokuNet(15, 64, 2), f16) is None
+    assert F.precision_for(nets.GomokuNet(15, 64, 30), f32) == "f32"      # 60 conv layers at 64 channels: the 32-cell-tile kernel
+    assert F.precision_for(nets.GomokuNet(15, 128, 30), f32) is None and F.precision_for(nets.GomokuNet(15, 128, 30), bf16) == "bf16"
+    assert F.precision_for(nets.GomokuNet(15, 96, 2), bf16) is None
+    assert F.quick_shape(nets.QuickNet(15, 9, 128, 4, 5)) == (15, 128, 4, 5) and F.quick_shape(nets.GomokuNet(15, 64, 2)) is None
+    assert F.precision_for(nets.QuickNet(9, 9, 64, 1, 5), f32) == "f32" and F.precision_for(nets.QuickNet(15, 9, 64, 9, 5), f32) is None
+    assert F.precision_for(nets.TicTacToeNet(), f32) is None
+    assert S.game_of(nets.TicTacToeNet()) == 0 and S.game_of(nets.DotsAndBoxesNet()) == 1 and S.game_of(nets.GomokuNet(9, 64, 1)) is None
+    assert evaluator_available(0, nets.TicTacToeNet(), f32) and not evaluator_available(0, nets.TicTacToeNet(), bf16)
+    assert evaluator_available(1, nets.DotsAndBoxesNet(), f32) and not evaluator_available(1, nets.TicTacToeNet(), f32)
+    assert evaluator_available(2, nets.QuickNet(15, 9, 128, 1, 5), bf16) and not evaluator_available(2, nets.QuickNet(3, 9, 128, 1, 5, n_action=9), f32)
