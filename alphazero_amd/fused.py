@@ -150,7 +150,7 @@ class FusedTowerEvaluator:
 
     def __init__(self, model: nn.Module, precision: str = "bf16"):
         """precision: "bf16" (az_tower.hip: bf16 operands, f32 accumulation -- the throughput mode) or "f32"
-        (az_tower_f32.hip: f32 MFMA, the reference's own arithmetic, 64-channel trunks).  The weights are folded and
+        (az_tower_f32.hip: f32 MFMA, the reference's own arithmetic).  The weights are folded and
         packed from the module's parameters in f32 either way, whatever dtype the module itself holds."""
         if not self.supports(model):
             raise EngineError("FusedTowerEvaluator: not a GomokuModel- or QuickModel-family network (64- or 128-channel 3x3 residual tower)")
