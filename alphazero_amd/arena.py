@@ -58,7 +58,10 @@ class SelfPlayRunner:
 
     def __init__(self, engine: Engine, model: torch.nn.Module, num_sims: int, alpha: float = ALPHA,
                  use_dirichlet: bool = True, reference_rng: bool = False, channels_last: bool = False,
-                 fused: bool = False, use_graph: bool = False):
+                 fused: bool = False, use_graph: bool = False, graph_unit: Optional[int] = None):
+        """graph_unit (with use_graph): simulation steps captured per HIP graph; None = the whole search of a move but its first
+        descent and last backup (one replay per move: on the small games a replay per step costs the host more than the step's
+        kernels take -- tic-tac-toe +27 %, dots-and-boxes +8 % measured)"""
         if num_sims > engine.max_sims:
             raise EngineError("num_sims exceeds the engine's max_sims")
         self.e, self.model, self.num_sims = engine, model, num_sims
@@ -79,6 +82,7 @@ class SelfPlayRunner:
         self.model_device = p.device if p is not None else torch.device("cpu")
         self.model_dtype = p.dtype if p is not None else torch.float32
         self.use_graph, self._graph = use_graph, None
+        self.graph_unit = max(1, min(int(graph_unit) if graph_unit else num_sims - 1, num_sims - 1)) if num_sims > 1 else 1
         self.fused = None
         if fused:  # hand-written MFMA network kernels (csrc/az_tower*.hip, csrc/az_smallnet.hip) instead of the module's own forward
             from .fused import FusedTowerEvaluator, SmallNetEvaluator
@@ -165,7 +169,8 @@ class SelfPlayRunner:
         gc.disable()
         try:
             with torch.cuda.graph(g):
-                self.eval_step(noise)
+                for _ in range(self.graph_unit):
+                    self.eval_step(noise)
         finally:
             if was_enabled:
                 gc.enable()
@@ -182,10 +187,13 @@ class SelfPlayRunner:
             self._capture(noise)
         e.begin_search()
         e.select_gather(None if self.fused is not None else self.nn_input)
-        for _ in range(self.num_sims - 1):
-            if self._graph is not None and self.use_graph:
+        if self._graph is not None and self.use_graph:
+            for _ in range((self.num_sims - 1) // self.graph_unit):
                 self._graph.replay()
-            else:
+            for _ in range((self.num_sims - 1) % self.graph_unit):
+                self.eval_step(noise)
+        else:
+            for _ in range(self.num_sims - 1):
                 self.eval_step(noise)
         self.evaluate()
         e.expand_backup(self.logits, self.values, noise)

@@ -161,7 +161,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
         ok = FusedTowerEvaluator.precision_for(model, tdtype) is not None  # (QuickModel family: f32 tower only)
         ok = ok or (game != 2 and tdtype == torch.float32 and SmallNetEvaluator.supports(model))  # az_smallnet.hip (f32 only)
         evaluator = "fused" if ok else "model"
-    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))
+    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph), graph_unit=args.graph_unit)
     if evaluator == "hash":  # tree kernels alone (no network)
         run.evaluate = lambda: eng.eval_hash(run.nn_input, run.logits, run.values, 6.0)
     wave = eng.leaves_per_step > 1  # virtual loss / in-tree leaf batching: several leaves per tree per network batch
@@ -334,7 +334,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     game_len = None
     if rank == 0 and with_probe and args.game_probe > 0 and evaluator != "hash":
         pe = Engine(game, args.game_probe, sims, board_size=n, nn_dtype=tdtype, device=dev, leaves_per_step=max(args.leaves, 1))
-        pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph))
+        pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph), graph_unit=args.graph_unit)
         pit = torch.full((args.game_probe,), 1.0 / reference_tao(0), device=dev)
         lengths, moves, tp0 = [], 0, time.perf_counter()
         while len(lengths) < args.game_probe and moves <= d.max_plies and time.perf_counter() - tp0 < 60.0:
@@ -567,6 +567,8 @@ def main():
                     "1: the timed steps replay the simulation step as a captured HIP graph "
                     "(what the small, launch-bound games want); the per-kernel HIP-event times then come from one eager probe "
                     "step run after the timed region.  0 (default): eager launches, events inside the timed region")
+    ap.add_argument("--graph-unit", type=int, default=0, help="simulation steps captured per HIP graph (one replay = that many steps); "
+                    "0 (default) = the whole search of a move")
     ap.add_argument("--leaves", type=int, default=1, help="leaves per tree per network batch: > 1 = virtual loss / in-tree leaf "
                     "batching (az_select_wave / az_expand_wave), which is not the reference's sequential search; reported without roofline")
     ap.add_argument("--preroll", type=int, default=96, help="cheap 2-sim move rounds that stagger game ages")
