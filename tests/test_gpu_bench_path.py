@@ -160,7 +160,7 @@ def test_runner_search_graph_replay_matches_eager(oracle, kind):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f32-quick", "bf16-quick"])
 def test_full_size_bench_path_properties(oracle, precision):
     """BASELINE configs[3] at its full size -- 16,384 gomoku-15 trees through SelfPlayRunner.search() with the fused tower on
     the packed + flags path -- checked through size-independent properties: two distinct root positions alternate over the
@@ -169,13 +169,14 @@ def test_full_size_bench_path_properties(oracle, precision):
     evaluator; visit sums, pi normalisation and the engine's counters hold for all slots."""
     from alphazero_amd import Engine
     from alphazero_amd.arena import SelfPlayRunner
-    from alphazero_amd.nets import GomokuNet
+    from alphazero_amd.nets import GomokuNet, QuickNet
 
     n, G, sims = 15, 16384, 20
     rng = np.random.default_rng(77)
     torch.manual_seed(5)
-    dtype = torch.bfloat16 if precision == "bf16" else torch.float32
-    net = _randomised(GomokuNet(n, 64, 2)).eval().cuda().to(dtype)
+    dtype = torch.bfloat16 if precision.startswith("bf16") else torch.float32
+    # (the QuickModel towers: every workgroup of a full grid runs dozens of boards through its stash region / residual registers)
+    net = _randomised(QuickNet(n, 9, 64, 1, 3) if precision.endswith("quick") else GomokuNet(n, 64, 2)).eval().cuda().to(dtype)
     eng = Engine(2, G, sims, board_size=n, nn_dtype=dtype, device="cuda:0")
     A = eng.dims.n_action
     pos = [_random_position(oracle, 2, n, m, rng) for m in (9, 30)]
