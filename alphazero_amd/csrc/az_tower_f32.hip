@@ -715,7 +715,24 @@ __global__ __launch_bounds__((64 * T16Geo<CW, N>::NW), (T16Geo<CW, N>::WG_PER_CU
     // re-derived from a laundered copy of the lane index inside each phase: left to itself the compiler hoists ~40 such
     // values out of the board loop, spills them, and reloads them right after a conv loop -- behind the weight requests in flight.
     auto corner_ptr = [&](int ln) { const int c = wave * 16 + (ln & 15); return (float *)(act + act_addr(LCELL, c >> 2) + (c & 3) * 4); };
-    auto shx = [](float t, int mask, int ln) { return __int_as_float(__builtin_amdgcn_ds_bpermute((ln ^ mask) << 2, __float_as_int(t))); };
+    // t + (t of lane ^ 16), t + (t of lane ^ 32): gfx950's row / half swaps instead of an LDS round trip (the two results of a swap
+    // are {own, partner} in one order or the other; the sum is the same bits either way); sum over a 16-lane row by rotations
+    // (after each step the values are symmetric under the bits already folded, so a rotation fetches what lane ^ off holds)
+    auto add16 = [](float t) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+      return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    };
+    auto add32 = [](float t) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+      return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    };
+    auto rowsum = [](float t) {
+      t = t + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
+      t = t + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
+      t = t + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x122, 0xF, 0xF, false));  // row_ror:2
+      t = t + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x121, 0xF, 0xF, false));  // row_ror:1
+      return t;
+    };
     auto init = [&](const float *b) {
       const int kq = fresh(lane) >> 4;
 #pragma unroll
@@ -728,8 +745,7 @@ __global__ __launch_bounds__((64 * T16Geo<CW, N>::NW), (T16Geo<CW, N>::WG_PER_CU
     };
     auto lfinal = [&](const float *b, bool with_res) {  // the four k quarters of cell 224, then bias (+ residual)
       const int ln = fresh(lane), lco = wave * 16 + (ln & 15);
-      lc = lc + shx(lc, 16, ln);
-      lc = lc + shx(lc, 32, ln);
+      lc = add32(add16(lc));
       lc = (with_res ? b[lco] + lres : b[lco]) + lc;
     };
     auto epilogue = [&]() {
@@ -997,8 +1013,7 @@ __global__ __launch_bounds__((64 * T16Geo<CW, N>::NW), (T16Geo<CW, N>::WG_PER_CU
 #pragma unroll
         for (int k = 0; k < 3; ++k) {  // sum over the four k-quarter groups (same order on every lane of a cell)
           float t = hs[pt][k];
-          t = t + shx(t, 16, ln);
-          t = t + shx(t, 32, ln);
+          t = add32(add16(t));
           hs[pt][k] = t;
         }
       FSTAMP(27);
@@ -1007,8 +1022,7 @@ __global__ __launch_bounds__((64 * T16Geo<CW, N>::NW), (T16Geo<CW, N>::WG_PER_CU
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           float t = a * hw[k * C + lco];
-#pragma unroll
-          for (int off = 8; off >= 1; off >>= 1) t = t + shx(t, off, ln);
+          t = rowsum(t);
           if (ln == 0) lh[wave * 3 + k] = t;
         }
       }
