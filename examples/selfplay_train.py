@@ -50,7 +50,11 @@ def main():
                              train_steps_per_move=args.train_steps_per_move, nn_dtype=dt_)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = loop.run(args.moves)
+    out = None
+    for m in range(args.moves):  # one line per move: a move of 16,384 games x 800 simulations takes minutes at the reference's precision
+        out = loop.run(1)
+        if rank == 0:
+            print(f"[selfplay_train] move {m + 1}/{args.moves}: {time.perf_counter() - t0:.1f} s, {out}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
