@@ -148,16 +148,17 @@ def test_runner_search_graph_replay_matches_eager(oracle, kind):
     pos = _positions(oracle, G, rng, n, 20)
     noise_np = rng.dirichlet([0.3] * (n * n), size=G).astype(np.float32)
     out = []
-    for graph in (False, True):
+    for graph in (False, True, 7):  # 7: graphs of seven simulation steps, 59 = 8 x 7 + 3 eager steps behind them
         eng = Engine(2, G, sims, board_size=n, nn_dtype=dt, device="cuda:0")
         for g, (h, p) in enumerate(pos):
             eng.set_position(g, h, p)
-        run = SelfPlayRunner(eng, net, sims, fused=True, use_graph=graph)
+        run = SelfPlayRunner(eng, net, sims, fused=True, use_graph=bool(graph), graph_unit=None if graph is True else graph)
         _fix_noise(run, noise_np)
         run.search()
         out.append(_results(eng))
-    for a, b in zip(*out):
-        assert np.array_equal(a, b)
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f32-quick", "bf16-quick"])
