@@ -58,8 +58,13 @@ class SelfPlayRunner:
 
     def __init__(self, engine: Engine, model: torch.nn.Module, num_sims: int, alpha: float = ALPHA,
                  use_dirichlet: bool = True, reference_rng: bool = False, channels_last: bool = False,
-                 fused: bool = False, use_graph: bool = False, graph_unit: Optional[int] = None):
-        """graph_unit (with use_graph): simulation steps captured per HIP graph; None = the whole search of a move but its first
+                 fused: bool = False, use_graph: bool = False, graph_unit: Optional[int] = None, seed: Optional[int] = None):
+        """seed: when given, the Dirichlet and Exponential rows are the engine's per-game counter-based rows (az_draw_rng:
+        Philox keyed on (seed, ``game_ids[slot]``, ply)) -- a game then plays the same moves whatever slot, slot count, rank
+        or world size it runs on; the caller keeps ``game_ids`` (int64, one global game id per slot) up to date when it
+        restarts slots.  None: rows from torch's device generator (or, with reference_rng, from torch's CPU generator in
+        the reference's order: training/alphazero_trainer.py:175-177, core/MCTS_alphazero.py:187, training/self_play.py:73-74).
+        graph_unit (with use_graph): simulation steps captured per HIP graph; None = the whole search of a move but its first
         descent and last backup (one replay per move: on the small games a replay per step costs the host more than the step's
         kernels take -- tic-tac-toe +27 %, dots-and-boxes +8 % measured)"""
         if num_sims > engine.max_sims:
@@ -78,6 +83,8 @@ class SelfPlayRunner:
         self.actions = torch.empty(G, dtype=torch.int32, device=dev)
         self.done = torch.empty(G, dtype=torch.uint8, device=dev)
         self._conc = torch.full((G, A), alpha, device=dev)
+        self.seed = None if seed is None else int(seed)
+        self.game_ids = torch.arange(G, dtype=torch.int64, device=dev)  # global game id of every slot (per-game RNG)
         p = next(model.parameters(), None)
         self.model_device = p.device if p is not None else torch.device("cpu")
         self.model_dtype = p.dtype if p is not None else torch.float32
@@ -125,6 +132,8 @@ class SelfPlayRunner:
 
             A = self.e.dims.n_action
             self.noise.copy_(Dirichlet(torch.ones(self.e.n_slots, A) * self.alpha).sample())
+        elif self.seed is not None:
+            self.e.draw_rng(self.seed, self.game_ids, noise=self.noise, alpha=self.alpha)
         else:
             self.noise.copy_(torch._sample_dirichlet(self._conc))
         return self.noise
@@ -132,6 +141,8 @@ class SelfPlayRunner:
     def draw_expo(self) -> torch.Tensor:
         if self.reference_rng:  # what torch.multinomial(w, 1) draws on CPU (ATen single-sample path)
             self.expo.copy_(torch.empty(self.expo.shape).exponential_(1))
+        elif self.seed is not None:  # (same ply as the move's Dirichlet row: drawn before az_play_moves advances it)
+            self.e.draw_rng(self.seed, self.game_ids, expo=self.expo)
         else:
             self.expo.exponential_(1)
         return self.expo
@@ -175,6 +186,7 @@ class SelfPlayRunner:
             if was_enabled:
                 gc.enable()
         self._graph, self._graph_noise = g, noise is not None
+        self._graph_gen = getattr(self.fused, "generation", 0)
 
     def search(self) -> None:
         """num_sims simulations in every active tree (MCTS.search, core/MCTS_alphazero.py:128-178): one descent, then
@@ -183,7 +195,8 @@ class SelfPlayRunner:
         e = self.e
         if e.leaves_per_step > 1:
             return self._search_waves(noise)
-        if self.use_graph and (self._graph is None or self._graph_noise != (noise is not None)):
+        if self.use_graph and (self._graph is None or self._graph_noise != (noise is not None)
+                               or self._graph_gen != getattr(self.fused, "generation", 0)):  # (a refresh() changed a by-value kernel argument)
             self._capture(noise)
         e.begin_search()
         e.select_gather(None if self.fused is not None else self.nn_input)
@@ -230,8 +243,11 @@ class ChessArena:
     def __init__(self, model_cls, game_cls, device: Optional[torch.device] = None, *, n_slots: int = 1024,
                  num_simulation: int = TRAIN_NUM_SIMULATION, c_puct: float = C_PUCT, epsilon: float = EPSILON,
                  alpha: float = ALPHA, nn_dtype: torch.dtype = torch.float32, fused: Optional[bool] = False,
-                 use_graph: bool = False) -> None:
-        """``fused``: False (default) = the module's own PyTorch-ROCm forward, whatever the module is -- a seeded run then
+                 use_graph: bool = False, seed: Optional[int] = None) -> None:
+        """``seed``: seed of the per-game counter-based RNG of ``self_play_many`` (every game's noise and move sampling are
+        a function of (seed, game id, ply) only: SelfPlayRunner); None = drawn once from torch's CPU generator, so
+        ``torch.manual_seed`` makes a run reproducible (the reference: SEED_BIAS + worker id, alphazero_trainer.py:175-177).
+        ``fused``: False (default) = the module's own PyTorch-ROCm forward, whatever the module is -- a seeded run then
         replays a seeded reference run move for move; True = the hand-written network kernels (alphazero_amd.fused: f32 towers
         at nn_dtype float32 -- the reference's arithmetic, agreeing with the module's forward to f32 rounding --, the bf16
         tower at bfloat16; raises if none covers the module); None = use them when one covers the module.  ``use_graph``:
@@ -248,6 +264,7 @@ class ChessArena:
         self.num_simulation, self.c_puct, self.epsilon, self.alpha = num_simulation, c_puct, epsilon, alpha
         self.n_slots, self.nn_dtype = n_slots, nn_dtype
         self.fused, self.use_graph = fused, use_graph
+        self.seed = int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
         self._engines: dict[int, Engine] = {}
         self.games_played = 0
 
@@ -273,7 +290,7 @@ class ChessArena:
 
     # ---- batched extension --------------------------------------------------------------------
     def self_play_many(self, n_games: int, tao: TaoSchedule, experience_pool, *, slots: Optional[int] = None,
-                       reference_rng: bool = False, trace: Optional[list] = None) -> dict:
+                       reference_rng: bool = False, trace: Optional[list] = None, game_ids: Optional[Sequence[int]] = None) -> dict:
         """Play n_games games, up to ``slots`` at a time; every finished game's samples go to
         ``experience_pool.put_tupule_experience`` exactly as training/self_play.py:110-139 puts them
         ((1,C_in,H,W) f32, (1,A) f32, (1,) f32 CPU tensors, last position first).  Pools that offer
@@ -281,7 +298,11 @@ class ChessArena:
 
         ``trace``: a list that receives one dict per move round -- the Dirichlet and Exponential rows the device drew
         for every slot, 1/tao, the actions played, the slots whose game ended (in the order their samples were put)
-        and the slots restarted -- enough to replay every game elsewhere (the parity tests do, on the CPU oracle)."""
+        and the slots restarted -- enough to replay every game elsewhere (the parity tests do, on the CPU oracle).
+
+        ``game_ids``: the global ids of the n_games games, in starting order (default: games_played, games_played + 1, ...;
+        a rank of a sharded run passes ``samples.games_for_rank``).  A game's random rows, and its temperature when ``tao``
+        is a schedule, depend on its id only -- not on the slot, the slot count or the rank that plays it."""
         slots = min(slots or self.n_slots, n_games)
         eng = self._engine(slots)
         fused = self.fused
@@ -292,8 +313,11 @@ class ChessArena:
         # (a new runner per call: a fused evaluator folds and packs the module's CURRENT weights here, so a load_model /
         # state_dict refresh between calls is picked up)
         run = SelfPlayRunner(eng, self.model, self.num_simulation, alpha=self.alpha, reference_rng=reference_rng, fused=bool(fused),
-                             use_graph=self.use_graph)
+                             use_graph=self.use_graph, seed=None if reference_rng else self.seed)
         d = eng.dims
+        ids = [self.games_played + i for i in range(n_games)] if game_ids is None else [int(i) for i in game_ids]
+        if len(ids) != n_games:
+            raise EngineError("game_ids must name exactly n_games games")
 
         def tao_of(i: int) -> float:
             if callable(tao):
@@ -303,9 +327,10 @@ class ChessArena:
             return float(tao[i])
 
         started = min(slots, n_games)
-        inv_tao_h = torch.tensor([1.0 / tao_of(self.games_played + i) if i < started else 1.0 for i in range(slots)],
-                                 dtype=torch.float32)
+        inv_tao_h = torch.tensor([1.0 / tao_of(ids[i]) if i < started else 1.0 for i in range(slots)], dtype=torch.float32)
         inv_tao = inv_tao_h.to(eng.device)
+        ids_h = torch.tensor([ids[i] if i < started else -1 for i in range(slots)], dtype=torch.int64)
+        run.game_ids.copy_(ids_h)
         eng.reset_games(None)
         finished = samples = 0
         put_batch = getattr(experience_pool, "put_batch", None)
@@ -320,11 +345,14 @@ class ChessArena:
             idx = torch.nonzero(done_h).reshape(-1)
             if trace is not None:
                 trace.append({"noise": run.noise.cpu().clone(), "expo": run.expo.cpu().clone(), "inv_tao": inv_tao.cpu().clone(),
-                              "actions": acts.cpu().clone(), "finished": idx.tolist(), "restarted": []})
+                              "actions": acts.cpu().clone(), "finished": idx.tolist(), "restarted": [], "game_ids": ids_h.clone(),
+                              "finished_ids": [], "finished_plies": []})
             if idx.numel() == 0:
                 continue
             plies, _, _, _ = eng.game_info()
             plies_h = plies.cpu()[idx]
+            if trace is not None:  # which games these are, and how many samples each one puts (in this order)
+                trace[-1]["finished_ids"], trace[-1]["finished_plies"] = ids_h[idx].tolist(), plies_h.tolist()
             states, pis, zs, offs = eng.emit_samples(idx.to(torch.int32), plies_h)
             states_h = states.view(-1, d.nn_channels, d.height, d.width).cpu()
             pis_h, zs_h = pis.cpu(), zs.cpu()
@@ -341,12 +369,14 @@ class ChessArena:
             for s in idx.tolist():
                 if started < n_games:
                     restart[s] = 1
-                    inv_tao_h[s] = 1.0 / tao_of(self.games_played + started)
+                    inv_tao_h[s] = 1.0 / tao_of(ids[started])
+                    ids_h[s] = ids[started]
                     started += 1
             if trace is not None:
                 trace[-1]["restarted"] = torch.nonzero(restart).reshape(-1).tolist()
             if bool(restart.any()):
                 inv_tao.copy_(inv_tao_h)
+                run.game_ids.copy_(ids_h)
                 eng.reset_games(restart.to(eng.device))
         eng.check()
         self.games_played += n_games

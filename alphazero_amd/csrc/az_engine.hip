@@ -911,6 +911,93 @@ __global__ __launch_bounds__(64) void k_augment(AugTables tb, const float *in_s,
   if (lane == 0) out_z[row] = in_z[i];
 }
 
+// ------------------------------------------------------------------------- per-game RNG -------
+// The reference seeds one torch generator per WORKER (training/alphazero_trainer.py:175-177) and draws, per move, a
+// Dirichlet(alpha) row (core/MCTS_alphazero.py:187) and the multinomial sample of training/self_play.py:73-74 (on ATen's
+// single-sample path: argmax(w / Exponential(1))).  Thousands of concurrent games cannot share a stream, and a stream per
+// slot would make a game's noise depend on where it happens to run.  Here every row is a pure function of
+// (seed, GLOBAL game id, ply, purpose): Philox4x32-10 with key = seed, counter = {element | attempt << 16,
+// ply | purpose << 16, game id lo, game id hi}.  A game therefore plays the same moves whatever slot, slot count, rank or
+// world size it lands on ("per-game RNG = Philox(seed, subsequence = game id)").
+//   Exponential(1):  -log(u),  u = ((w0 >> 9) + 0.5) * 2^-23 in (0, 1)
+//   Gamma(alpha <= 1, 1) by Ahrens-Dieter GS (uniforms, exp, log only; no normals): b = (e + alpha) / e; repeat
+//     P = b U;  P <= 1: X = P^(1/alpha), accept if W <= exp(-X);  else X = -log((b - P) / alpha), accept if W <= X^(alpha-1)
+//   with a fresh Philox block per attempt; Dirichlet = Gamma row / its sum (the engine's wave-order sum).
+// exp / log are the fmaf polynomials above, so oracle/az_oracle.c (az_oracle_draw_rng) reproduces every row bit for bit.
+// Not torch's Dirichlet stream: the tables stay DATA at the ABI (az_expand_backup / az_play_moves take any rows), and a
+// seeded replay of the reference uses rows drawn by torch (SelfPlayRunner(reference_rng=True)).
+struct Philox { uint32_t c[4]; };
+__host__ __device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox{{c0, c1, c2, c3}};
+}
+__device__ __forceinline__ float rng_u01(uint32_t w) { return ((float)(w >> 9) + 0.5f) * 1.1920928955078125e-07f; }  // (0, 1), exact
+__device__ __forceinline__ float rng_pow(float x, float y) {  // x > 0, result <= 1 wanted: exp(min(y log x, 0))
+  float t = y * az_logf(x);
+  if (t > 0.0f) t = 0.0f;
+  return az_expf(t);
+}
+enum : uint32_t { RNG_DIRICHLET = 0u, RNG_EXPO = 1u };
+constexpr int RNG_MAX_ATTEMPTS = 64;
+
+__device__ __forceinline__ float rng_gamma(float alpha, float inv_alpha, float b, uint32_t a, uint32_t c1, uint32_t g0, uint32_t g1,
+                                           uint32_t k0, uint32_t k1) {
+  for (int t = 0; t < RNG_MAX_ATTEMPTS; ++t) {
+    const Philox r = philox4x32_10(a | ((uint32_t)t << 16), c1, g0, g1, k0, k1);
+    const float U = rng_u01(r.c[0]), W = rng_u01(r.c[1]);
+    const float P = b * U;
+    if (P <= 1.0f) {
+      const float X = rng_pow(P, inv_alpha);
+      if (W <= az_expf(-X)) return X;
+    } else {
+      const float rest = (b - P) / alpha;
+      if (!(rest > 0.0f)) continue;
+      const float X = -az_logf(rest);
+      if (X > 0.0f && W <= rng_pow(X, alpha - 1.0f)) return X;
+    }
+  }
+  return 1.0e-30f;  // (probability ~ 1e-30 per element: never seen; keeps the row finite)
+}
+
+template <class GT>
+__global__ __launch_bounds__(64) void k_draw_rng(View v, unsigned long long seed, const long long *gameIds, float alpha, float *noise,
+                                                 float *expo) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  constexpr int A = GT::A, NI = (A + 63) / 64;
+  if (!v.active[g]) return;
+  const unsigned long long gid = (unsigned long long)gameIds[g];
+  const uint32_t g0 = (uint32_t)gid, g1 = (uint32_t)(gid >> 32), k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const uint32_t ply = (uint32_t)v.ply[g];
+  if (expo) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int a = lane + 64 * i;
+      if (a < A) expo[(size_t)g * A + a] = -az_logf(rng_u01(philox4x32_10((uint32_t)a, ply | (RNG_EXPO << 16), g0, g1, k0, k1).c[0]));
+    }
+  }
+  if (noise) {
+    const float inv_alpha = 1.0f / alpha, b = (2.7182817459106445f + alpha) / 2.7182817459106445f;
+    float x[NI], acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int a = lane + 64 * i;
+      x[i] = a < A ? rng_gamma(alpha, inv_alpha, b, (uint32_t)a, ply | (RNG_DIRICHLET << 16), g0, g1, k0, k1) : 0.0f;
+      acc = acc + x[i];
+    }
+    const float tot = wave_sum(acc);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int a = lane + 64 * i;
+      if (a < A) noise[(size_t)g * A + a] = x[i] / tot;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------- small kernels ------
 template <class GT>
 __global__ void k_reset_games(View v, const uint8_t *mask) {
@@ -1476,6 +1563,22 @@ int az_augment_samples(az_engine *e, int32_t n, const float *states_dev, const f
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_augment<GT>), dim3(n, 8), dim3(64), 0, (hipStream_t)stream, tb, states_dev, pis_dev, z_dev,
                                     out_states_dev, out_pis_dev, out_z_dev, (long long)ring_capacity, (long long)ring_write_idx));
   return launch_check(e, "k_augment");
+}
+
+int az_draw_rng(az_engine *e, uint64_t seed, const int64_t *game_ids_dev, float alpha, float *noise_dev, float *expo_dev, void *stream) {
+  if (!e || !game_ids_dev || (!noise_dev && !expo_dev)) return AZ_EINVAL;
+  if (noise_dev && !(alpha > 0.0f && alpha <= 1.0f)) { e->err = "az_draw_rng: the Dirichlet sampler takes 0 < alpha <= 1 (ALPHA = 0.3, config/basic.py:13)"; return AZ_EINVAL; }
+  DeviceGuard guard(e->cfg.device);
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_draw_rng<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, (unsigned long long)seed,
+                                    (const long long *)game_ids_dev, alpha, noise_dev, expo_dev));
+  return launch_check(e, "k_draw_rng");
+}
+
+int az_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+  if (!counter || !key || !out) return AZ_EINVAL;
+  const az::Philox r = az::philox4x32_10(counter[0], counter[1], counter[2], counter[3], key[0], key[1]);
+  for (int i = 0; i < 4; ++i) out[i] = r.c[i];
+  return AZ_OK;
 }
 
 int az_read_stats(az_engine *e, az_stats *out, void *stream) {

@@ -1005,9 +1005,11 @@ void tower_set_error(const std::string &msg) { g_tower_err = msg; }  // (az_towe
 // cannot overlap, hence:
 //   - eager launches: one pair per (GPU, stream) -- launches on one stream run in order; pairs 0 .. EAGER-1, looked up in
 //     a small table (least recently used entry recycled when more than EAGER streams have launched towers on the GPU);
-//   - launches recorded into a HIP graph (stream capture): each gets a pair of its own from EAGER .. PAIRS-1, round
-//     robin, never handed to an eager stream -- a graph replays with the pair baked in, on whatever stream replays it.
-//     (More than PAIRS - EAGER captured tower launches alive at once may share pairs: replay those graphs on one stream.)
+//   - launches recorded into a HIP graph (stream capture): ONE pair per capture (keyed on the capture id of
+//     hipStreamGetCaptureInfo; the launches inside one capture are serialised by the graph's edges, and a search graph
+//     holds hundreds of them), from EAGER .. PAIRS-1, round robin over captures, never handed to an eager stream -- a graph
+//     replays with the pair baked in, on whatever stream replays it.  (More than PAIRS - EAGER graphs with tower launches
+//     alive at once on one GPU share pairs: replay those on one stream.  INTEGRATION.md states the rule.)
 // A __device__ array exists once per GPU; its address is looked up per device, for the device that owns the stream.
 #define AZ_TOWER_TICKET_PAIRS 64
 #define AZ_TOWER_EAGER_PAIRS 32
@@ -1020,6 +1022,7 @@ struct TicketDev {
   int n_streams;
   unsigned long long clock;
   unsigned int cap_seq;
+  unsigned long long cap_id[AZ_TOWER_TICKET_PAIRS - AZ_TOWER_EAGER_PAIRS];  // capture id that owns each graph pair (0 = none yet)
   unsigned int attr_done;  // bit k: hipFuncSetAttribute issued for kernel variant k on this GPU
 };
 static TicketDev g_td[64];
@@ -1031,6 +1034,20 @@ int tower_device(hipStream_t stream, int *dev) {  // (also used by az_tower_f32.
   (void)hipGetLastError();
   return hipGetDevice(dev) == hipSuccess ? 0 : -1;
 }
+
+// Launches belong to the stream's GPU, whatever device the calling thread has current: every entry point of the network
+// kernels (towers AND heads) holds one of these for its whole body and puts the caller's device back on the way out.
+struct StreamDeviceGuard {
+  int dev = -1, back = -1;
+  bool ok = false;
+  explicit StreamDeviceGuard(hipStream_t s) {
+    int cur = 0;
+    if (tower_device(s, &dev) != 0 || dev < 0 || dev >= 64 || hipGetDevice(&cur) != hipSuccess) return;
+    if (dev != cur) { if (hipSetDevice(dev) != hipSuccess) return; back = cur; }
+    ok = true;
+  }
+  ~StreamDeviceGuard() { if (back >= 0) (void)hipSetDevice(back); }
+};
 
 // -> the ticket pair of this launch, or nullptr (message in g_tower_err).  `dev` is current.
 unsigned int *tower_tickets(int dev, hipStream_t stream) {  // (also used by az_tower_f32.hip)
@@ -1045,9 +1062,17 @@ unsigned int *tower_tickets(int dev, hipStream_t stream) {  // (also used by az_
     t.base = (unsigned int *)p;
   }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (stream != nullptr && hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-  if (cs == hipStreamCaptureStatusActive)
-    return t.base + 2 * (AZ_TOWER_EAGER_PAIRS + (t.cap_seq++ % (AZ_TOWER_TICKET_PAIRS - AZ_TOWER_EAGER_PAIRS)));
+  unsigned long long cid = 0;
+  if (stream != nullptr && hipStreamGetCaptureInfo(stream, &cs, &cid) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+  if (cs == hipStreamCaptureStatusActive) {
+    constexpr unsigned int NG = AZ_TOWER_TICKET_PAIRS - AZ_TOWER_EAGER_PAIRS;
+    const unsigned long long key = cid + 1;  // (0 marks an unused entry)
+    for (unsigned int i = 0; i < NG; ++i)
+      if (t.cap_id[i] == key) return t.base + 2 * (AZ_TOWER_EAGER_PAIRS + i);
+    const unsigned int slot = t.cap_seq++ % NG;  // a new capture: the next pair, round robin
+    t.cap_id[slot] = key;
+    return t.base + 2 * (AZ_TOWER_EAGER_PAIRS + slot);
+  }
   ++t.clock;
   int slot = -1;
   for (int i = 0; i < t.n_streams; ++i)
@@ -1114,6 +1139,8 @@ int az_heads_forward(int32_t board_size, int32_t n_boards, const void *feat_bf16
   const int ntp = (board_size * board_size + 31) / 32;
   const dim3 grid((n_boards + 31) / 32, (ntp + 3) / 4 + 1), block(256);  // k_heads: 32 boards x one job (4 policy tiles | value) per workgroup
   hipStream_t s = (hipStream_t)stream;
+  StreamDeviceGuard sguard(s);
+  if (!sguard.ok) { g_tower_err = "cannot select the stream's device"; return AZ_EHIP; }
   if (board_size == 15)
     hipLaunchKernelGGL((k_heads<225>), grid, block, 0, s, (const uint16_t *)feat_bf16_dev, (int)feat_stride, (int)n_boards, (const char *)wp_dev,
                        bp_dev, (const char *)w1_dev, b1_dev, w2_dev, b2, logits_dev, values_dev);
@@ -1214,16 +1241,9 @@ int az_tower_heads_forward_static(int32_t board_size, int32_t channels, int32_t 
     return AZ_EINVAL;
   }
   hipStream_t s = (hipStream_t)stream;
-  int dev = 0, cur = 0;
-  if (tower_device(s, &dev) != 0 || dev < 0 || dev >= 64) { g_tower_err = "cannot tell the stream's device"; return AZ_EHIP; }
-  if (hipGetDevice(&cur) != hipSuccess) { g_tower_err = "hipGetDevice failed"; return AZ_EHIP; }
-  unsigned char *feat = nullptr;
-  {
-    const bool sw = dev != cur;
-    if (sw) (void)hipSetDevice(dev);
-    feat = static_scratch(dev);  // this GPU's copy of the array (looked up on the first call, or by az_create before)
-    if (sw) (void)hipSetDevice(cur);
-  }
+  StreamDeviceGuard sguard(s);  // the stream's GPU stays current across the memset, the tower and the heads
+  if (!sguard.ok) { g_tower_err = "cannot select the stream's device"; return AZ_EHIP; }
+  unsigned char *feat = static_scratch(sguard.dev);  // this GPU's copy of the array (looked up on the first call, or by az_create before)
   if (feat == nullptr) return AZ_EHIP;
   const int32_t stride = az_heads_feat_stride(board_size);
   // the array keeps the last call's contents (another board size has another row layout): the pad columns the kernels
@@ -1318,6 +1338,8 @@ int az_quick_heads_forward(int32_t board_size, int32_t n_boards, const void *fea
   if (feat_stride < az_heads_feat_stride(board_size) || (feat_stride & 7)) { g_tower_err = "feat_stride: a multiple of 8, at least az_heads_feat_stride(board_size)"; return AZ_EINVAL; }
   const dim3 grid((n_boards + 31) / 32), block(256);
   hipStream_t s = (hipStream_t)stream;
+  StreamDeviceGuard sguard(s);
+  if (!sguard.ok) { g_tower_err = "cannot select the stream's device"; return AZ_EHIP; }
   if (board_size == 15)
     hipLaunchKernelGGL((k_quick_heads<225>), grid, block, 0, s, (const uint16_t *)feat_bf16_dev, (int)feat_stride, (int)n_boards, (const char *)w1p_dev,
                        b1p_dev, (const char *)w2p_dev, b2p_dev, (const char *)w1v_dev, b1v_dev, w2v_dev, b2v, logits_dev, values_dev);

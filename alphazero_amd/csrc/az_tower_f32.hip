@@ -40,6 +40,21 @@ int tower_device(hipStream_t stream, int *dev);             // az_tower.hip
 unsigned int *tower_tickets(int dev, hipStream_t stream);   // az_tower.hip
 void tower_set_error(const std::string &msg);               // az_tower.hip
 
+// (as in az_tower.hip) a launch belongs to the stream's GPU, whatever device the calling thread has current
+namespace {
+struct StreamDeviceGuard {
+  int dev = -1, back = -1;
+  bool ok = false;
+  explicit StreamDeviceGuard(hipStream_t s) {
+    int cur = 0;
+    if (tower_device(s, &dev) != 0 || dev < 0 || dev >= 64 || hipGetDevice(&cur) != hipSuccess) return;
+    if (dev != cur) { if (hipSetDevice(dev) != hipSuccess) return; back = cur; }
+    ok = true;
+  }
+  ~StreamDeviceGuard() { if (back >= 0) (void)hipSetDevice(back); }
+};
+}  // namespace
+
 namespace aztf32 {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -1241,6 +1256,8 @@ int az_heads_forward_f32(int32_t board_size, int32_t n_boards, const float *feat
   const int ntp = (board_size * board_size + 31) / 32;
   const dim3 grid((n_boards + 31) / 32, (ntp + 3) / 4 + 1), block(256);
   hipStream_t s = (hipStream_t)stream;
+  StreamDeviceGuard sguard(s);
+  if (!sguard.ok) { tower_set_error("cannot select the stream's device"); return AZ_EHIP; }
   if (board_size == 15)
     hipLaunchKernelGGL((k_heads_f32<225>), grid, block, 0, s, feat_dev, (int)feat_stride, (int)n_boards, (const char *)wp_dev, bp_dev,
                        (const char *)w1_dev, b1_dev, w2_dev, b2, logits_dev, values_dev);
@@ -1401,6 +1418,8 @@ int az_quick_heads_forward_f32(int32_t board_size, int32_t n_boards, const float
   if (feat_stride < az_heads_feat_stride(board_size) || (feat_stride & 3)) { tower_set_error("feat_stride: a multiple of 4, at least az_heads_feat_stride(board_size)"); return AZ_EINVAL; }
   const dim3 grid((n_boards + 31) / 32), block(256);
   hipStream_t s = (hipStream_t)stream;
+  StreamDeviceGuard sguard(s);
+  if (!sguard.ok) { tower_set_error("cannot select the stream's device"); return AZ_EHIP; }
   if (board_size == 15)
     hipLaunchKernelGGL((k_quick_heads_f32<225>), grid, block, 0, s, feat_dev, (int)feat_stride, (int)n_boards, (const char *)w1p_dev, b1p_dev,
                        (const char *)w2p_dev, b2p_dev, (const char *)w1v_dev, b1v_dev, w2v_dev, b2v, logits_dev, values_dev);

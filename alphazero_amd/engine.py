@@ -44,7 +44,7 @@ EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check"
            "az_tower_heads_forward_static", "az_static_max_boards", "az_tower_forward_f32", "az_heads_forward_f32",
            "az_select_wave", "az_expand_wave", "az_search_remaining", "az_set_virtual_loss", "az_smallnet_forward_f32",
            "az_quick_tower_forward_f32", "az_quick_heads_forward_f32", "az_quick_stash_bytes", "az_quick_tower_forward", "az_quick_heads_forward",
-           "az_smallnet_head_floats"]
+           "az_smallnet_head_floats", "az_draw_rng", "az_philox4x32_10"]
 
 _lib = None
 
@@ -107,6 +107,8 @@ def load_library() -> C.CDLL:
     lib.az_expand_wave.argtypes = [vp, vp, vp, vp, vp]
     lib.az_search_remaining.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp]
     lib.az_set_virtual_loss.argtypes = [vp, C.c_double]
+    lib.az_draw_rng.argtypes = [vp, C.c_uint64, vp, C.c_float, vp, vp, vp]
+    lib.az_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
     for name in EXPORTS:
@@ -357,6 +359,16 @@ class Engine:
         self._ck(self.lib.az_play_moves(self._h, _ptr(inv_tao), _ptr(expo), _ptr(forced), _ptr(actions), _ptr(done),
                                         self._stream()))
         return actions, done
+
+    def draw_rng(self, seed: int, game_ids, noise=None, expo=None, alpha: float = 0.3):
+        """per-game counter-based rows (az_draw_rng): Dirichlet(alpha) into ``noise`` and / or Exponential(1) into ``expo``
+        for every active slot, keyed on (seed, game_ids[slot], the slot's ply)"""
+        A, G = self.dims.n_action, self.n_slots
+        self._expect(game_ids, (G,), torch.int64, "game_ids")
+        self._expect(noise, (G, A), torch.float32, "noise")
+        self._expect(expo, (G, A), torch.float32, "expo")
+        self._ck(self.lib.az_draw_rng(self._h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _ptr(game_ids), C.c_float(alpha),
+                                      _ptr(noise), _ptr(expo), self._stream()))
 
     def game_info(self):
         G = self.n_slots

@@ -69,6 +69,18 @@ def _pack_linear_f32(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
     return t.permute(0, 2, 3, 1, 4).contiguous().float()
 
 
+def _keep(obj, name: str, t: torch.Tensor, dev) -> None:
+    """obj.<name> = t on ``dev`` -- IN PLACE when the attribute already holds a tensor of that shape and dtype.  A HIP graph
+    captured by SelfPlayRunner(use_graph=True) has the packed weights' device addresses baked in: a refresh() after a weight
+    publish must therefore rewrite the same allocations (shapes never change between refreshes of one module), not replace
+    them -- a replay would go on reading the old, freed blocks."""
+    old = getattr(obj, name, None)
+    if isinstance(old, torch.Tensor) and old.shape == t.shape and old.dtype == t.dtype and old.device == torch.device(dev):
+        old.copy_(t)
+    else:
+        setattr(obj, name, t.to(dev).contiguous())
+
+
 class FusedTowerEvaluator:
     @staticmethod
     def quick_shape(model: nn.Module):
@@ -183,6 +195,16 @@ class FusedTowerEvaluator:
         self.kernel_events = None  # bench.py sets this to a list: (start, end) HIP events around the tower kernel alone
         self.refresh()
 
+    generation = 0  # bumped when a refresh() changes something a captured HIP graph holds BY VALUE (a kernel argument)
+
+    def _set_scalar(self, name: str, value: float) -> None:
+        """the value head's last bias travels to the kernel as an argument: a graph captured before the refresh keeps the
+        old number, so SelfPlayRunner re-captures when ``generation`` has moved (the packed tensors are rewritten in place
+        and need no re-capture)"""
+        if getattr(self, name, value) != value:
+            self.generation += 1
+        setattr(self, name, value)
+
     @torch.no_grad()
     def _refresh_quick(self) -> None:
         m, dev, n2 = self.model, self.device, self.n2
@@ -190,7 +212,7 @@ class FusedTowerEvaluator:
         f32 = self.precision == "f32"
         pack3, packl = (_pack3x3_f32, _pack_linear_f32) if f32 else (_pack3x3, _pack_linear)
         w, b = _fold(sl[0], sl[1])
-        self.w0 = pack3(w, 16).to(dev)
+        _keep(self, "w0", pack3(w, 16), dev)
         biases, wl = [b], []
         for blk in sl[3:]:
             seq = list(blk.model)
@@ -199,26 +221,26 @@ class FusedTowerEvaluator:
                 wl.append(pack3(w, self.ch))
                 biases.append(b)
         self.n_layers = len(wl)
-        self.wl = torch.stack(wl).to(dev).contiguous()
-        self.bias = torch.stack(biases).to(dev).contiguous()
+        _keep(self, "wl", torch.stack(wl), dev)
+        _keep(self, "bias", torch.stack(biases), dev)
         ph, vh = list(m._policy_head), list(m._value_head)
         pw, pb = _fold(ph[0], ph[1])  # (2, ch, 3, 3)
         vw, vb = _fold(vh[0], vh[1])  # (1, ch, 3, 3)
         # [3 head channels][9 taps][ch] f32: policy0, policy1, value
-        self.headw = torch.cat([pw, vw]).permute(0, 2, 3, 1).reshape(3, 9, self.ch).to(dev).contiguous()
-        self.headb = torch.cat([pb, vb]).to(dev).contiguous()
-        f = lambda t: t.detach().float().to(dev).contiguous()
+        _keep(self, "headw", torch.cat([pw, vw]).permute(0, 2, 3, 1).reshape(3, 9, self.ch), dev)
+        _keep(self, "headb", torch.cat([pb, vb]), dev)
+        f = lambda t: t.detach().float()
         self.kpq, self.kvq = (2 * n2 + 15) // 16 * 16, (n2 + 15) // 16 * 16
         self.feat_stride = int(self.lib.az_heads_feat_stride(self.board))
         assert self.feat_stride == self.kpq + self.kvq
-        self.w1p = packl(f(ph[4].weight), 64, self.kpq).to(dev)
-        self.b1p = f(ph[4].bias)
-        self.w2p = packl(f(ph[6].weight), (n2 + 31) // 32 * 32, 64).to(dev)
-        self.b2p = f(ph[6].bias)
-        self.w1v = packl(f(vh[4].weight), 64, self.kvq).to(dev)
-        self.b1v = f(vh[4].bias)
-        self.w2v = f(vh[6].weight).reshape(-1)
-        self.b2v = float(vh[6].bias.detach().float().reshape(-1)[0])
+        _keep(self, "w1p", packl(f(ph[4].weight), 64, self.kpq), dev)
+        _keep(self, "b1p", f(ph[4].bias), dev)
+        _keep(self, "w2p", packl(f(ph[6].weight), (n2 + 31) // 32 * 32, 64), dev)
+        _keep(self, "b2p", f(ph[6].bias), dev)
+        _keep(self, "w1v", packl(f(vh[4].weight), 64, self.kvq), dev)
+        _keep(self, "b1v", f(vh[4].bias), dev)
+        _keep(self, "w2v", f(vh[6].weight).reshape(-1), dev)
+        self._set_scalar("b2v", float(vh[6].bias.detach().float().reshape(-1)[0]))
         if f32 and getattr(self, "stash", None) is None:  # block inputs in flight: one private region per workgroup of a full grid
             self.stash_bytes = int(self.lib.az_quick_stash_bytes(self.board, self.ch))
             if self.stash_bytes <= 0:
@@ -235,7 +257,7 @@ class FusedTowerEvaluator:
         f32 = self.precision == "f32"
         pack3 = _pack3x3_f32 if f32 else _pack3x3
         w, b = _fold(sl[0], sl[1])
-        self.w0 = pack3(w, 16).to(dev)
+        _keep(self, "w0", pack3(w, 16), dev)
         biases, wl = [b], []
         for blk in blocks:
             for conv, bn in ((blk._conv1, blk._bn1), (blk._conv2, blk._bn2)):
@@ -243,13 +265,13 @@ class FusedTowerEvaluator:
                 wl.append(pack3(w, self.ch))
                 biases.append(b)
         self.n_layers = len(wl)
-        self.wl = (torch.stack(wl) if wl else torch.zeros(1, dtype=self.in_dtype)).to(dev).contiguous()
-        self.bias = torch.stack(biases).to(dev).contiguous()
+        _keep(self, "wl", torch.stack(wl) if wl else torch.zeros(1, dtype=self.in_dtype), dev)
+        _keep(self, "bias", torch.stack(biases), dev)
         pw, pb = _fold(m._policy_head[0], m._policy_head[1])
         vw, vb = _fold(m._value_head[0], m._value_head[1])
-        self.headw = torch.cat([pw.view(1, self.ch), vw.view(2, self.ch)]).to(dev).contiguous()
-        self.headb = torch.cat([pb.view(1), vb.view(2)]).to(dev).contiguous()
-        f = lambda t: t.detach().float().to(dev).contiguous()
+        _keep(self, "headw", torch.cat([pw.view(1, self.ch), vw.view(2, self.ch)]), dev)
+        _keep(self, "headb", torch.cat([pb.view(1), vb.view(2)]), dev)
+        f = lambda t: t.detach().float()
         pl, v1, v2 = m._policy_head[4], m._value_head[4], m._value_head[6]
         if v1.out_features != 64 or v2.out_features != 1:
             raise EngineError("FusedTowerEvaluator: the value head must be Linear(2 N*N, 64) -> Linear(64, 1)")
@@ -258,12 +280,12 @@ class FusedTowerEvaluator:
         self.feat_stride = int(self.lib.az_heads_feat_stride(self.board))
         assert self.feat_stride == self.kp + self.kv
         packl = _pack_linear_f32 if f32 else _pack_linear
-        self.wp = packl(f(pl.weight), (n2 + 31) // 32 * 32, self.kp).to(dev)
-        self.bp = f(pl.bias)
-        self.w1 = packl(f(v1.weight), 64, self.kv).to(dev)
-        self.b1 = f(v1.bias)
-        self.w2 = f(v2.weight).reshape(-1)
-        self.b2 = float(v2.bias.detach().float().reshape(-1)[0])
+        _keep(self, "wp", packl(f(pl.weight), (n2 + 31) // 32 * 32, self.kp), dev)
+        _keep(self, "bp", f(pl.bias), dev)
+        _keep(self, "w1", packl(f(v1.weight), 64, self.kv), dev)
+        _keep(self, "b1", f(v1.bias), dev)
+        _keep(self, "w2", f(v2.weight).reshape(-1), dev)
+        self._set_scalar("b2", float(v2.bias.detach().float().reshape(-1)[0]))
 
     def __call__(self, x: torch.Tensor | None, logits_out: torch.Tensor | None = None, packed=None, n_boards: int = 0):
         """x: contiguous (B,9,N,N) bf16 batch, or None with packed = (ring, leaf[, list, count[, flags]]) from
@@ -363,11 +385,12 @@ class FusedTowerEvaluator:
             if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape or t.device != self.device:
                 raise EngineError(f"forward_static: outputs must be contiguous float32 {shape} tensors on the model's GPU")
         P = lambda t: C.c_void_p(t.data_ptr())
-        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = self.lib.az_tower_heads_forward_static(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p,
-                                                    leaf_p, flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.headw),
-                                                    P(self.headb), P(self.wp), P(self.bp), P(self.w1), P(self.b1), P(self.w2),
-                                                    self.b2, P(logits), P(values), st)
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            rc = self.lib.az_tower_heads_forward_static(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p,
+                                                        leaf_p, flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.headw),
+                                                        P(self.headb), P(self.wp), P(self.bp), P(self.w1), P(self.b1), P(self.w2),
+                                                        self.b2, P(logits), P(values), st)
         if rc != 0:
             raise EngineError(f"az_tower_heads_forward_static failed ({rc}): {self.lib.az_tower_last_error().decode()}")
         return logits, values
@@ -379,6 +402,8 @@ class SmallNetEvaluator:
     (csrc/az_smallnet.hip: both convs, both heads, tanh; a workgroup per 7 / 4 boards, activations in LDS).  Same call
     contract as FusedTowerEvaluator: ``(B, C_in, H, W) f32`` or the engine's packed leaf batch ->
     ``(logits (B, A) f32, value (B, 1) f32)``; f32 operands and accumulation, the reference's precision."""
+
+    generation = 0  # (as FusedTowerEvaluator.generation: nothing here travels to the kernel by value, so it never moves)
 
     @staticmethod
     def game_of(model: nn.Module):
@@ -439,10 +464,10 @@ class SmallNetEvaluator:
         m, dev = self.model, self.device
         f = lambda t: t.detach().float().cpu()
         sl, ph, vh = list(m._shared_layers), list(m._policy_head), list(m._value_head)
-        self.w1 = self._pack3x3(f(sl[0].weight), self.cinp).to(dev)
-        self.b1 = f(sl[0].bias).to(dev).contiguous()
-        self.w2 = self._pack3x3(f(sl[2].weight), 64).to(dev)
-        self.b2 = f(sl[2].bias).to(dev).contiguous()
+        _keep(self, "w1", self._pack3x3(f(sl[0].weight), self.cinp), dev)
+        _keep(self, "b1", f(sl[0].bias), dev)
+        _keep(self, "w2", self._pack3x3(f(sl[2].weight), 64), dev)
+        _keep(self, "b2", f(sl[2].bias), dev)
         if self.game == 0:
             w = torch.cat([f(ph[1].weight), f(vh[1].weight)])  # (192, 576), column c * 9 + pos (Flatten of (64, 3, 3))
             w = w.view(192, 64, 9).permute(2, 1, 0).reshape(36, 4, 4, 192)  # [pos * 4 + m][kq][j][n]: channel 16 m + 4 kq + j
@@ -453,7 +478,7 @@ class SmallNetEvaluator:
                      f(ph[3].weight), f(ph[3].bias), f(vh[3].weight), f(vh[3].bias), f(vh[5].weight), f(vh[5].bias)]
         head = torch.cat([p.contiguous().reshape(-1) for p in parts])
         assert head.numel() == int(self.lib.az_smallnet_head_floats(self.game))
-        self.head = head.to(dev).contiguous()
+        _keep(self, "head", head, dev)
 
     def __call__(self, x: torch.Tensor | None, logits_out: torch.Tensor | None = None, packed=None, n_boards: int = 0):
         if x is not None:

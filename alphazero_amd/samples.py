@@ -61,7 +61,12 @@ class WeightPublisher:
             for t in self.tensors:
                 self.flat[off:off + t.numel()].copy_(t.reshape(-1))
                 off += t.numel()
-        dist.broadcast(self.flat, src=self.src)
+        if dist.get_backend() == "gloo" and self.flat.is_cuda:  # rehearsal backend: the collective runs on a host copy
+            h = self.flat.cpu()
+            dist.broadcast(h, src=self.src)
+            self.flat.copy_(h)
+        else:
+            dist.broadcast(self.flat, src=self.src)  # RCCL over xGMI
         if dist.get_rank() != self.src:
             off = 0
             for t in self.tensors:

@@ -37,8 +37,10 @@ def gpu_self_player_worker(model_cls, game_cls, model_state, experience_pool, nu
         torch.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
         dev = device or torch.device("cuda", worker_id % max(torch.cuda.device_count(), 1))
+        # the worker's seed also keys its games' counter-based random rows (arena.seed): workers get distinct streams as in the
+        # reference, and a worker's game k plays the same moves whatever n_slots is
         arena = ChessArena(model_cls, game_cls, dev, n_slots=n_slots, num_simulation=num_simulation, fused=fused, use_graph=use_graph,
-                           nn_dtype=nn_dtype)
+                           nn_dtype=nn_dtype, seed=seed)
         sync_model_from_shared(arena.model, model_state, model_lock)
         # one "generation" = n_slots concurrent games at the temperature the reference's worker would use for its
         # generation-th game; weights are refreshed every SELF_PLAY_UPDATE_MODEL_FREQUENCY generations' worth of games

@@ -130,11 +130,12 @@ def cpu_baseline(workload: str, budget_s: float = 12.0) -> dict:
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
 
 
-def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_probe=True):
+def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=True):
     """One timed self-play run of the workload at one network precision -> dict of results (rank 0) / None."""
     import torch
     import torch.distributed as dist
 
+    use_dist = dst is not None
     from alphazero_amd import Engine
     from alphazero_amd.arena import END_TEMPERATURE, START_TEMPERATURE, TEMPERATURE_DECAY, SelfPlayRunner, reference_tao
     from alphazero_amd.engine import copy_to_host
@@ -149,8 +150,12 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
         model = model.to(tdtype)
     model = model.to(memory_format=torch.channels_last)
     publisher = WeightPublisher(model, src=0)
-    torch.manual_seed(1234 + rank)  # same weights on every rank (make_model seeds 0), different games: per-rank RNG streams
+    torch.manual_seed(1234 + rank)  # (only the agreement probe's opening moves still draw from torch's generators)
     torch.cuda.manual_seed(1234 + rank)
+    # Dirichlet / Exponential rows: the engine's per-game counter-based RNG (az_draw_rng), Philox(seed = 1234) keyed on the
+    # GLOBAL game id and the ply -- slot g of rank r starts with game r + world * g, the k-th game a rank
+    # starts later is r + world * k: the same games are played whatever the number of GPUs they are spread over
+    SEED = 1234
 
     eng = Engine(game, slots, sims, board_size=n, nn_dtype=tdtype, device=dev, leaves_per_step=max(args.leaves, 1))
     d = eng.dims
@@ -161,7 +166,9 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
         ok = FusedTowerEvaluator.precision_for(model, tdtype) is not None  # (QuickModel family: f32 tower only)
         ok = ok or (game != 2 and tdtype == torch.float32 and SmallNetEvaluator.supports(model))  # az_smallnet.hip (f32 only)
         evaluator = "fused" if ok else "model"
-    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph), graph_unit=args.graph_unit)
+    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph), graph_unit=args.graph_unit,
+                         seed=SEED)
+    run.game_ids.copy_(rank + world * torch.arange(slots, dtype=torch.int64))
     if evaluator == "hash":  # tree kernels alone (no network)
         run.evaluate = lambda: eng.eval_hash(run.nn_input, run.logits, run.values, 6.0)
     wave = eng.leaves_per_step > 1  # virtual loss / in-tree leaf batching: several leaves per tree per network batch
@@ -170,6 +177,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
 
     copy_stream = torch.cuda.Stream(dev)
     games_started = slots
+    ids_started = slots  # game ids this rank has handed out (id = rank + world * k)
     inv_tao_h = torch.tensor([1.0 / reference_tao(0)] * slots, dtype=torch.float32).pin_memory()
     inv_tao = inv_tao_h.to(dev)
     finished_games = 0
@@ -188,7 +196,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
 
     def collect(done):
         """emit + D2H the samples of the games that just ended, restart their slots"""
-        nonlocal games_started, finished_games, finished_plies
+        nonlocal games_started, ids_started, finished_games, finished_plies
         plies, _, _, _ = eng.game_info()
         both = torch.stack((done.to(torch.int32), plies)).cpu()  # the move's one host sync
         idx = torch.nonzero(both[0]).reshape(-1)
@@ -213,6 +221,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
         finished_games += nf
         finished_plies += int(plies_h.sum())
         # per-slot temperature schedule restarts with the new game (reference_tao, vectorised)
+        run.game_ids[idx.to(dev)] = (rank + world * (ids_started + torch.arange(nf, dtype=torch.int64))).to(dev)
+        ids_started += nf
         k = (games_started + torch.arange(nf)) // slots
         inv_tao_h[idx] = (1.0 / torch.clamp(START_TEMPERATURE * TEMPERATURE_DECAY ** k.double(), min=END_TEMPERATURE)).float()
         games_started += nf
@@ -225,7 +235,10 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
         ar = torch.arange(slots, device=dev)
         for r in range(R):
             _, done = run.move_round(inv_tao)
-            eng.reset_games(((ar % R == r) | (done != 0)).to(torch.uint8))
+            again = (ar % R == r) | (done != 0)
+            eng.reset_games(again.to(torch.uint8))
+            run.game_ids += again.to(torch.int64) * (world * slots)  # a restarted slot is a new game: a fresh id of this rank's residue class
+            ids_started += slots  # (ids below rank + world * ids_started are taken)
         run.num_sims = sims
         eng.check()
 
@@ -280,7 +293,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     finished_games = finished_plies = 0
     torch.cuda.synchronize()
     if use_dist:
-        dist.barrier()
+        dst.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -288,7 +301,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     finalize_pending()  # the last move's samples belong to the timed region
     torch.cuda.synchronize()
     if use_dist:
-        dist.barrier()
+        dst.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     eng.check()
@@ -306,8 +319,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     tt = torch.tensor([elapsed, float(st["sims"]), float(finished_games), float(finished_plies)], dtype=torch.float64, device=dev)
     if use_dist:
         tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dst.all_reduce(tmax, dist.ReduceOp.MAX)
+        dst.all_reduce(tt, dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
     total_sims, total_games, total_plies = float(tt[1]), float(tt[2]), float(tt[3])
 
@@ -334,7 +347,9 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, use_dist, with_pr
     game_len = None
     if rank == 0 and with_probe and args.game_probe > 0 and evaluator != "hash":
         pe = Engine(game, args.game_probe, sims, board_size=n, nn_dtype=tdtype, device=dev, leaves_per_step=max(args.leaves, 1))
-        pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph), graph_unit=args.graph_unit)
+        pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph), graph_unit=args.graph_unit,
+                            seed=SEED)
+        pr.game_ids += 1 << 40  # (games of their own, outside every rank's id range)
         pit = torch.full((args.game_probe,), 1.0 / reference_tao(0), device=dev)
         lengths, moves, tp0 = [], 0, time.perf_counter()
         while len(lengths) < args.game_probe and moves <= d.max_plies and time.perf_counter() - tp0 < 60.0:
@@ -547,6 +562,105 @@ def decision_agreement(args, dev, n_pos=1024, plies=12):
                    "distance between the two root visit distributions"}
 
 
+# ------------------------------------------------------------------------------ N ranks --------
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list, dry_run: bool) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start N rank processes of this script, one per GPU (the
+    reference's scale-out is N spawned self-play workers, training/alphazero_trainer.py:395-456, workers :420-433; here a
+    worker owns a GPU).  Runs BEFORE anything imports torch: this parent never touches a GPU, never execs, and never
+    restarts a child.  Rank 0's stdout (the JSON line) is relayed; the exit code is the worst of the children's; when a
+    rank dies the others are ended (by their own PIDs) instead of waiting in a collective for it."""
+    import subprocess
+    import threading
+
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AZ_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        capture = r == 0 or dry_run
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if capture else subprocess.DEVNULL, text=True))
+    lines = [[] for _ in range(n)]
+
+    def relay(r):
+        for line in procs[r].stdout:
+            lines[r].append(line)
+            if not dry_run:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+
+    readers = [threading.Thread(target=relay, args=(r,), daemon=True) for r in range(n) if procs[r].stdout is not None]
+    for t in readers:
+        t.start()
+    worst = 0
+    live = set(range(n))
+    while live:
+        time.sleep(0.2)
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                print(f"[bench] rank {r} exited with code {rc}: ending the other ranks", file=sys.stderr, flush=True)
+                for o in sorted(live):
+                    procs[o].terminate()
+    for t in readers:
+        t.join(timeout=5.0)
+    if dry_run:  # one JSON list: what every rank saw
+        print(json.dumps([json.loads(l[-1]) for l in lines if l]))
+    return worst
+
+
+class Dist:
+    """the few collectives the bench needs, on RCCL (backend "nccl") or -- for a 2-rank rehearsal on a one-GPU box, where
+    RCCL refuses two ranks on one device -- on gloo through host tensors"""
+
+    def __init__(self, backend, rank, world, dev):
+        import torch.distributed as dist
+
+        self.dist, self.backend, self.rank, self.world, self.dev = dist, backend, rank, world, dev
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def all_reduce(self, t, op):
+        """t: a device tensor; reduced in place over the ranks"""
+        if self.backend == "nccl":
+            self.dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=op)
+            t.copy_(h)
+        return t
+
+    def gather_objects(self, obj):
+        out = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -579,9 +693,32 @@ def main():
     ap.add_argument("--no-agreement", action="store_true", help="skip the f32-vs-bf16 decision-agreement measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the "
                     "barrier / all-reduce / weight-broadcast path on a one-GPU box")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI, one rank per GPU (the measured "
+                    "configuration).  gloo: the same N-rank code path with the collectives on host tensors, ranks may share a GPU "
+                    "(local rank modulo the visible GPUs): a rehearsal of the N > 1 logic on a one-GPU box, not a measurement")
+    ap.add_argument("--launch-dry-run", action="store_true", help="every rank prints the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* it "
+                    "was started with and exits before anything touches a GPU (test of the launcher)")
     args = ap.parse_args()
     if args.graph < 0:
         args.graph = 1 if WORKLOADS[args.workload][3] <= 4096 and args.leaves <= 1 and args.evaluator != "hash" else 0
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # `python bench.py --gpus N` with no launcher around it: become the launcher (before torch is imported; this process
+    # never touches a GPU) and let N children of this script be the ranks
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.launch_dry_run))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under "
+                 f"torch.distributed.run with --nproc-per-node equal to --gpus")
+    if args.launch_dry_run:
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master_addr": os.environ.get("MASTER_ADDR"),
+                          "master_port": os.environ.get("MASTER_PORT"), "pid": os.getpid(), "torch_imported": "torch" in sys.modules}))
+        return
 
     # a line on stderr every 45 s: the deep configurations run minutes between two outputs, and a harness that watches for
     # silence would take them for hung
@@ -591,13 +728,10 @@ def main():
     def _heartbeat():
         while True:
             time.sleep(45.0)
-            print(f"[bench] running, {time.perf_counter() - t_start:.0f} s", file=sys.stderr, flush=True)
+            print(f"[bench] rank {rank} running, {time.perf_counter() - t_start:.0f} s", file=sys.stderr, flush=True)
 
-    threading.Thread(target=_heartbeat, daemon=True).start()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        threading.Thread(target=_heartbeat, daemon=True).start()
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and args.cpu_baseline_seconds > 0:
@@ -606,26 +740,27 @@ def main():
         cpu = cpu_baseline(args.workload, args.cpu_baseline_seconds if world == 1 else min(args.cpu_baseline_seconds, 6.0))
 
     import torch
-    import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        sys.exit("bench.py: no GPU visible (there is no CPU path)")
+    if local_rank >= n_dev and args.dist_backend == "nccl":
+        sys.exit(f"bench.py: local rank {local_rank} has no GPU of its own ({n_dev} visible): RCCL needs one GPU per rank "
+                 "(--dist-backend gloo rehearses the N-rank path with ranks sharing a GPU)")
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dst = Dist(args.dist_backend, rank, world, dev) if (world > 1 or args.force_dist) else None
 
-    kw = WORKLOADS[args.workload][4]
     primary = args.dtype
     if primary == "auto":
         primary = "f32"  # the reference's own arithmetic; every workload has an f32 evaluator (hand-written tower or the module's forward)
-    out = measure(args, primary, args.steps, args.warmup, dev, rank, world, use_dist)
+    out = measure(args, primary, args.steps, args.warmup, dev, rank, world, dst)
     sec_steps = args.secondary_steps if args.secondary_steps >= 0 else (min(args.steps, 4) if world == 1 else 0)
     second = None
     if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1:
-        second = measure(args, "bf16", sec_steps, 1, dev, rank, world, use_dist)
+        second = measure(args, "bf16", sec_steps, 1, dev, rank, world, dst)
+    ranks_seen = dst.gather_objects({"rank": rank, "device": dev_index, "pid": os.getpid()}) if dst is not None else None
     if rank == 0:
         out["cpu_baseline"] = cpu
         if cpu:
@@ -639,10 +774,18 @@ def main():
             if not args.no_agreement:
                 second["decision_agreement"] = decision_agreement(args, dev)
             out["throughput_mode"] = second
-        print(json.dumps(out))
-    if use_dist:
-        dist.barrier()  # rank 0 arrives last (game-length probe, printing): every rank leaves the group together
-        dist.destroy_process_group()
+        elif world > 1:
+            out["throughput_mode"] = None
+            out["throughput_mode_why"] = ("the bf16 line, the decision-agreement measurement and the game-length probe of the other "
+                                          "precision run at one GPU only (--secondary-steps K forces the bf16 line at N > 1)")
+        if dst is not None:  # who really took part: one rank per entry, with the device ordinal it ran on
+            out["rccl_ranks"] = len(ranks_seen)
+            out["dist_backend"] = "rccl (torch.distributed 'nccl')" if args.dist_backend == "nccl" else "gloo (host tensors; rehearsal, ranks may share a GPU)"
+            out["devices"] = [r["device"] for r in sorted(ranks_seen, key=lambda r: r["rank"])]
+            out["launched_by"] = "bench.py --gpus N (own launcher)" if os.environ.get("AZ_BENCH_LAUNCHED") else "external launcher (torch.distributed.run)"
+        print(json.dumps(out), flush=True)
+    if dst is not None:
+        dst.close()  # rank 0 arrives last (game-length probe, printing): every rank leaves the group together
 
 
 if __name__ == "__main__":

@@ -179,6 +179,23 @@ int az_root_nn_state(az_engine *e, float *nn_state_dev, void *stream);
 int az_play_moves(az_engine *e, const float *inv_tao_dev, const float *expo_dev,
                   const int32_t *forced_actions_dev, int32_t *actions_dev, uint8_t *done_dev, void *stream);
 
+/* Per-game, counter-based random rows ("per-game RNG = Philox(seed, subsequence = game id)").  The
+ * reference seeds one torch generator per worker (training/alphazero_trainer.py:175-177) and draws per move a
+ * Dirichlet(ALPHA) row (core/MCTS_alphazero.py:187) and the multinomial sample of training/self_play.py:73-74
+ * (= argmax(w / Exponential(1))).  Here, for every ACTIVE slot g, the rows are a pure function of
+ * (seed, game_ids_dev[g], the slot's current ply, purpose) -- Philox4x32-10, key = seed, counter = {element | attempt << 16,
+ * ply | purpose << 16, game id} -- so a game plays the same moves on any slot, slot count, rank or world size.
+ *   noise_dev (n_slots, A) f32 or NULL: Dirichlet(alpha) rows (0 < alpha <= 1: Gamma by Ahrens-Dieter GS, normalised) for
+ *   az_expand_backup / az_expand_select; expo_dev (n_slots, A) f32 or NULL: Exponential(1) rows for az_play_moves.
+ *   game_ids_dev (n_slots) i64: the global game id of each slot (rank + world * k for the k-th game of a rank).
+ * Rows of inactive slots are left untouched.  NOT torch's random stream (bit-equality with torch's Dirichlet is not
+ * claimed: the tables remain data at this ABI, and a seeded replay of the reference feeds rows drawn by torch);
+ * restated bit for bit in oracle/az_oracle.c (az_oracle_draw_rng).  az_philox4x32_10: the block function on the host
+ * (Random123 known-answer vectors are checked against it). */
+int az_draw_rng(az_engine *e, uint64_t seed, const int64_t *game_ids_dev, float alpha, float *noise_dev, float *expo_dev,
+                void *stream);
+int az_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+
 /* Per-slot game info, device-to-device copies into caller buffers (any may be NULL):
  * plies i32, player to move i32, active u8, result f32 (outcome from the last mover's view,
  * training/self_play.py:86-89; valid once done). */

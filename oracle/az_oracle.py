@@ -215,3 +215,26 @@ def get_prior(game, board_size, logits, mask, noise=None, epsilon=0.25):
 
 def powf(x, y):
     return float(lib().az_oracle_powf(C.c_float(x), C.c_float(y)))
+
+
+def philox4x32_10(counter, key):
+    """the Philox4x32-10 block function (az_oracle_philox4x32_10)"""
+    c = (C.c_uint32 * 4)(*[int(x) & 0xFFFFFFFF for x in counter])
+    k = (C.c_uint32 * 2)(*[int(x) & 0xFFFFFFFF for x in key])
+    out = (C.c_uint32 * 4)()
+    lib().az_oracle_philox4x32_10(c, k, out)
+    return [int(x) for x in out]
+
+
+def draw_rng(seed, game_id, ply, n_action, alpha=0.3, want_noise=True, want_expo=True):
+    """the per-game random rows of game ``game_id`` at ply ``ply`` (az_oracle_draw_rng == the engine's az_draw_rng):
+    -> (noise (A,) Dirichlet(alpha) or None, expo (A,) Exponential(1) or None)"""
+    noise = np.zeros(n_action, np.float32) if want_noise else None
+    expo = np.zeros(n_action, np.float32) if want_expo else None
+    fn = lib().az_oracle_draw_rng
+    fn.restype = C.c_int
+    rc = fn(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int64(int(game_id)), C.c_int(ply), C.c_int(n_action), C.c_float(alpha),
+            _p(noise, _f32p), _p(expo, _f32p))
+    if rc != 0:
+        raise ValueError(f"az_oracle_draw_rng failed: {rc}")
+    return noise, expo

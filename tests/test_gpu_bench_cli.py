@@ -50,3 +50,25 @@ def test_bench_line_small_game_fused_and_through_pytorch():
     assert "k_smallnet_f32" in kernels and d["roofline_tree"]["kernel"] == "k_expand_select"
     d = _run(base + ["--evaluator", "model"])  # the module's own PyTorch forward: the tree kernel's HBM roofline leads
     assert d["roofline"]["kernel"] == "k_expand_select" and "PyTorch" in d["nn_eval"]["implementation"]
+
+
+def test_bench_gpus_2_launches_two_ranks_gloo_rehearsal():
+    """`python bench.py --gpus 2` as the driver calls it: the script launches its own two ranks.  On a one-GPU box RCCL refuses
+    two ranks on one device, so the collectives run on gloo (--dist-backend gloo) with both ranks sharing cuda:0: this runs
+    measure()'s N > 1 branches -- barrier pair, MAX / SUM all-reduce of the timings, weight broadcast + refresh of the fused
+    tower before every move, rank-0-only game-length probe while rank 1 waits, the final barrier -- with world = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--slots", "128", "--sims", "16",
+           "--steps", "2", "--warmup", "1", "--preroll", "4", "--game-probe", "16", "--cpu-baseline-seconds", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0's)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["devices"] == [0, 0] and "gloo" in d["dist_backend"]
+    assert d["launched_by"].startswith("bench.py")
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["cpu_baseline"]["value"] > 0
+    # whole-job aggregate: both ranks' simulations over the slowest rank's time
+    per_rank_sims = 128 * 16 * 2
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - 2 * per_rank_sims) <= 0.02 * 2 * per_rank_sims
+    assert d["throughput_mode"] is None and "one GPU" in d["throughput_mode_why"]

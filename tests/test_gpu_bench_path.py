@@ -161,6 +161,76 @@ def test_runner_search_graph_replay_matches_eager(oracle, kind):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kind", ["gomokunet-f32", "quicknet-bf16", "dab-smallnet"])
+def test_graph_replay_after_weight_refresh_matches_eager(oracle, kind):
+    """A weight publish between two moves: ``refresh()`` re-folds the module's new weights into the evaluator's packed tensors.
+    A search graph captured BEFORE the refresh has those tensors' addresses baked in, so the refresh must rewrite them in place
+    (and re-capture only for what travels by value): the replayed search after the refresh == an eager search with a freshly
+    built evaluator on the new weights, bit for bit -- and differs from the search on the old weights."""
+    from alphazero_amd import Engine
+    from alphazero_amd.arena import SelfPlayRunner
+    from alphazero_amd.nets import DotsAndBoxesNet, GomokuNet, QuickNet
+
+    rng = np.random.default_rng(31)
+    torch.manual_seed(8)
+    if kind == "dab-smallnet":
+        game, n, G, sims, dt = 1, 3, 64, 40, torch.float32
+        mk = lambda: DotsAndBoxesNet()
+    else:
+        game, n, G, sims = 2, 9, 48, 40
+        dt = torch.float32 if kind.endswith("f32") else torch.bfloat16
+        mk = lambda: _randomised(QuickNet(n, 9, 64, 2, 2) if kind.startswith("quick") else GomokuNet(n, 64, 2))
+    net = mk().eval().cuda().to(dt)
+    new_weights = {k: v.clone() for k, v in mk().eval().cuda().to(dt).state_dict().items()}
+    A = Engine(game, 1, 1, board_size=n, device="cuda:0").dims.n_action
+    noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
+
+    def fresh_engine():
+        e = Engine(game, G, sims, board_size=n, nn_dtype=dt, device="cuda:0")
+        if game == 2:
+            for g, (h, p) in enumerate(pos):
+                e.set_position(g, h, p)
+        return e
+
+    pos = _positions(oracle, G, rng, n, 20) if game == 2 else None
+
+    def restart(e):
+        if game == 2:
+            for g, (h, p) in enumerate(pos):
+                e.set_position(g, h, p)
+        else:
+            e.reset_games(None)
+
+    eng = fresh_engine()
+    run = SelfPlayRunner(eng, net, sims, fused=True, use_graph=True)
+    _fix_noise(run, noise_np)
+    run.search()  # captures the graph on the OLD weights
+    old = _results(eng)
+    g0, gen0 = run._graph, run.fused.generation
+    assert g0 is not None
+    names = ("w1", "w2", "head", "w0", "wl", "bias", "headw", "wp", "w1p", "w2p")
+    ptrs = {k: getattr(run.fused, k).data_ptr() for k in names if isinstance(getattr(run.fused, k, None), torch.Tensor)}
+    assert ptrs
+    net.load_state_dict(new_weights)
+    run.fused.refresh()
+    assert all(getattr(run.fused, k).data_ptr() == p for k, p in ptrs.items()), "refresh() must rewrite the packed weights in place"
+    restart(eng)
+    run.search()  # same runner, same engine: the old graph replays unless a by-value argument changed (then it is re-captured)
+    assert (run._graph is g0) == (run.fused.generation == gen0)
+    replayed = _results(eng)
+    eng.close()
+
+    eng = fresh_engine()
+    run2 = SelfPlayRunner(eng, net, sims, fused=True, use_graph=False)
+    _fix_noise(run2, noise_np)
+    run2.search()
+    eager = _results(eng)
+    eng.close()
+    for a, b in zip(replayed, eager):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(old[1], eager[1]), "the two weight sets must lead to different searches for the test to mean anything"
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f32-quick", "bf16-quick"])
 def test_full_size_bench_path_properties(oracle, precision):
     """BASELINE configs[3] at its full size -- 16,384 gomoku-15 trees through SelfPlayRunner.search() with the fused tower on

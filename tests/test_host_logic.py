@@ -403,3 +403,25 @@ def test_fused_kernel_selection_is_decided_from_the_module_alone():
     assert evaluator_available(0, nets.TicTacToeNet(), f32) and not evaluator_available(0, nets.TicTacToeNet(), bf16)
     assert evaluator_available(1, nets.DotsAndBoxesNet(), f32) and not evaluator_available(1, nets.TicTacToeNet(), f32)
     assert evaluator_available(2, nets.QuickNet(15, 9, 128, 1, 5), bf16) and not evaluator_available(2, nets.QuickNet(3, 9, 128, 1, 5, n_action=9), f32)
+
+
+def test_bench_launcher_starts_one_rank_per_gpu_before_any_gpu_call():
+    """`python bench.py --gpus 2` with no launcher around it becomes the launcher: two children of the same script with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, started before torch is imported (--launch-dry-run returns there).
+    The scale-out it stands for: training/alphazero_trainer.py:395-456 (one spawned worker per unit of hardware)."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-dry-run"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ranks = json.loads(out.stdout.strip().splitlines()[-1])
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["local_rank"] for r in ranks] == [0, 1]
+    assert all(r["world"] == 2 and r["master_addr"] == "127.0.0.1" and not r["torch_imported"] for r in ranks)
+    assert ranks[0]["master_port"] == ranks[1]["master_port"] and ranks[0]["pid"] != ranks[1]["pid"]
+    # a world size that does not match --gpus is refused, loudly (the flag is not decoration)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-dry-run"],
+                         env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr

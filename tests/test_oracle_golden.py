@@ -132,3 +132,48 @@ def test_augmentation_kat(tag):
             assert np.array_equal(outs[t].reshape(-1).astype(np.int8), z[f"{tag}__out_states"][8 * i + t]), (i, t)
             assert np.array_equal(outp[t], z[f"{tag}__out_pis"][8 * i + t]), (i, t)
             assert outz[t] == z[f"{tag}__out_z"][8 * i + t]
+
+
+# ---------------------------------------------------------------- per-game random rows (az_draw_rng) ----
+PHILOX_KAT = [  # Random123 known-answer vectors for philox4x32-10: (counter, key, output)
+    ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+    ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+    ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0], [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+]
+
+
+def test_philox_known_answers_oracle_and_library(oracle):
+    """the block function behind the per-game rows, in the oracle's restatement and in the product library's host export,
+    against the published Random123 vectors (the generator is a third-party algorithm: Salmon et al., SC'11)"""
+    import ctypes as C
+
+    from alphazero_amd.engine import load_library
+
+    lib = load_library()
+    for ctr, key, want in PHILOX_KAT:
+        assert oracle.philox4x32_10(ctr, key) == want
+        out = (C.c_uint32 * 4)()
+        assert lib.az_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out) == 0
+        assert list(out) == want
+
+
+def test_per_game_rows_are_a_function_of_seed_game_and_ply_with_the_right_distribution(oracle):
+    A = 9
+    n0, e0 = oracle.draw_rng(7, 3, 2, A)
+    n1, e1 = oracle.draw_rng(7, 3, 2, A)
+    assert np.array_equal(n0, n1) and np.array_equal(e0, e1)
+    for other in ((8, 3, 2), (7, 4, 2), (7, 3, 3), (7, 3 + 2 ** 32, 2)):
+        n2, e2 = oracle.draw_rng(*other, A)
+        assert not np.array_equal(n0, n2) and not np.array_equal(e0, e2)
+    # a longer row starts with other values only through the normalisation: the Exponential row is a prefix
+    assert np.array_equal(oracle.draw_rng(7, 3, 2, 24)[1][:A], e0)
+    ns = np.stack([oracle.draw_rng(1, g, 0, A)[0] for g in range(20000)])
+    es = np.stack([oracle.draw_rng(1, g, 0, A)[1] for g in range(20000)])
+    assert np.all(es > 0) and abs(es.mean() - 1.0) < 0.01 and abs(es.var() - 1.0) < 0.03  # Exponential(1)
+    assert np.allclose(ns.sum(1), 1.0, atol=1e-5) and np.all(ns >= 0)
+    a0 = 0.3 * A  # Dirichlet(0.3 * 1_A): mean 1/A, variance (1/A)(1 - 1/A) / (a0 + 1)
+    assert np.all(np.abs(ns.mean(0) - 1.0 / A) < 0.005)
+    assert abs(ns.var(0).mean() - (1.0 / A) * (1 - 1.0 / A) / (a0 + 1)) < 0.001
+    ref = np.random.default_rng(0).dirichlet([0.3] * A, 20000)[:, 0]
+    for q in (0.25, 0.5, 0.9, 0.99):  # the marginal is Beta(0.3, 2.4): quantiles against numpy's sampler
+        assert abs(np.quantile(ns[:, 0], q) - np.quantile(ref, q)) < 0.02
