@@ -2,12 +2,22 @@
 //
 // Data layout in HBM (all owned by the engine, allocated once in az_create):
 //   per tree g (one per game slot), a bump-allocated pool of CHILD RECORDS ("edges"), struct of arrays,
-//   tree-major so that the children of one node are one contiguous, coalesced run:
-//     edgeQ    f64  [G][E]   child.value (running mean, the child's own point of view); NOT written at expansion:
-//                            a record with visits == 0 has value 0.0 by definition, whatever the bytes say
-//     edgePN   2x32 [G][E]   {prior of the child (the parent's prior[0, action]) f32, child.visits i32}
-//     edgeMeta u32  [G][E]   action (bits 0-8) | child.player == parent.player (bit 9) |
-//                            1 + first edge of the child's own block once it is expanded (bits 10-31)
+//   tree-major so that the children of one node are one contiguous, coalesced run.  A record has a LIGHT part, written
+//   at expansion and read for every child a descent scans, and a HEAVY part that exists only once the child has been
+//   TOUCHED (chosen by a descent at least once):
+//     edgeP    f32  [G][E]   prior of the child (the parent's prior[0, action])                       light, 4 B
+//     edgeAct  u8   [G][E]   action of the child (every game here has A <= 256)                       light, 1 B
+//     edgeNM   2x32 [G][E]   {child.visits i32, meta u32}                                             heavy, 8 B
+//                            meta = touched children of the child's OWN block (bits 0-8) |
+//                            child.player == parent.player (bit 9) | 1 + first edge of the child's block (bits 10-31)
+//     edgeQ    f64  [G][E]   child.value (running mean, the child's own point of view)                heavy, 8 B
+//   An untouched child has visits 0 and value 0.0 by definition, so its PUCT score needs its prior only: a descent
+//   reads 5 B per untouched child and 21 B per touched one.  To know WHICH records are touched without a dependent
+//   load, a block keeps its touched records first -- positions [0, t) in order of first touch, [t, count) untouched --
+//   and t travels with the pointer to the block (the parent record's meta; rootV for the root's block): the descent
+//   that first chooses record j >= t swaps it with record t, initialises its heavy part {0 visits, 0.0} and bumps t.
+//   Records are therefore NOT in action order: ties of the PUCT score are broken on the action itself (strict '>' in
+//   the reference's loop over ascending actions = lowest action wins).
 //   A node's block holds one record per legal action, and every game here has exactly
 //   PMAX - (moves played) legal actions in a non-terminal position, so a block needs no length field and
 //   there is no node table: the root's block starts at edge 0.
@@ -46,6 +56,19 @@ namespace az {
 
 enum : int { KIND_EVAL = 0, KIND_TERMINAL = 1 };
 constexpr int WAVE_KMAX = 16;  // most leaves per tree per step
+// Trees per workgroup of the per-simulation kernels (one wavefront each).  A CU takes at most 16 workgroups at a time,
+// so one-wave workgroups leave it at 16 resident waves whatever the registers allow (measured: 3.7 waves per SIMD, the
+// launch 40 % longer than its waves' lifetimes add up to); with 4 trees per workgroup residency is register-bound.
+// The waves of a workgroup share nothing and never meet at a barrier (wave_sync).
+#ifndef AZ_TREE_WPB
+#define AZ_TREE_WPB 4
+#endif
+constexpr int TREE_WPB = AZ_TREE_WPB;
+#ifdef AZ_TREE_OCC  // ask for at least this many waves per SIMD (register budget 512 / AZ_TREE_OCC)
+#define AZ_TREE_BOUNDS __launch_bounds__(64 * TREE_WPB, AZ_TREE_OCC)
+#else
+#define AZ_TREE_BOUNDS __launch_bounds__(64 * TREE_WPB)
+#endif
 enum : int { ERR_EDGE_CAP = 1, ERR_NODE_CAP = 2, ERR_DEPTH_CAP = 4, ERR_ILLEGAL = 8, ERR_NO_ROOT = 16, ERR_EMIT_SETPOS = 32 };
 
 struct View {  // kernel argument: raw device pointers + sizes
@@ -55,10 +78,12 @@ struct View {  // kernel argument: raw device pointers + sizes
   double vl;    // VIRTUAL_LOSS (config/basic.py:25), used by the wave kernels only
   int32_t *waveCnt;              // [G] leaves queued by the last k_select_wave
   unsigned long long *remain;    // [2] {sum, max} of simulations left (az_search_remaining)
-  double *edgeQ;
-  int2 *edgePN;
-  uint32_t *edgeMeta;
+  float *edgeP;       // light: prior
+  uint8_t *edgeAct;   // light: action
+  int2 *edgeNM;       // heavy: {visits, meta}
+  double *edgeQ;      // heavy: value
   int32_t *edgeCnt;
+  int32_t *rootV;     // [G] touched records of the root's block
   int32_t *rootN;
   double *rootQ;
   int32_t *path;
@@ -75,11 +100,12 @@ struct View {  // kernel argument: raw device pointers + sizes
   int32_t *player;
   uint8_t *active;
   float *result;
-  unsigned long long *stat;  // [G][6]
+  unsigned long long *stat;  // [G][NSTAT]
   int32_t *err;
 };
 
-constexpr uint32_t META_ACT = 0x1FFu, META_SAME = 0x200u;
+constexpr uint32_t META_V = 0x1FFu, META_SAME = 0x200u;  // META_V: touched records of the child's own block
+constexpr int NSTAT = 8;  // per-slot counters: sims, depth, children scanned, evals, terminals, expanded, touched scanned, -
 constexpr int META_KID_SHIFT = 10;
 constexpr int MAX_EDGE_CAP = (1 << 22) - 2;
 
@@ -141,6 +167,19 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Counters of a slot: lane k < 7 owns counter k.  A kernel loads its lane's counter with its first batch of loads, the
+// bodies add to the register, and the kernel stores it on the way out: no dependent load at the end of a wave's life (a
+// load / add / store per counter by lane 0 was one), no atomics (16,384 x 7 of them per launch cost more than they saved).
+struct StatAcc {
+  unsigned long long v = 0;
+  unsigned long long *p = nullptr;
+  __device__ __forceinline__ void load(unsigned long long *st, int lane) { if (lane < 7) { p = st + lane; v = *p; } }
+  __device__ __forceinline__ void add(int lane, unsigned long long x0, unsigned long long x1, unsigned long long x2, unsigned long long x3,
+                                      unsigned long long x4, unsigned long long x5, unsigned long long x6) {
+    v += lane == 0 ? x0 : lane == 1 ? x1 : lane == 2 ? x2 : lane == 3 ? x3 : lane == 4 ? x4 : lane == 5 ? x5 : x6;
+  }
+  __device__ __forceinline__ void store() { if (p) *p = v; }
+};
 
 template <typename T> __device__ __forceinline__ T cvt_out(float v);
 template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
@@ -191,11 +230,20 @@ __device__ __forceinline__ void load_ring(const uint32_t *tb, int ply, uint32_t 
 // current board.  k_expand_select fills it while the expansion of the previous simulation runs (the words are the
 // ones the expansion reads or writes anyway, the ring only depends on the ply), so the descent starts without the
 // two memory round trips a stand-alone k_select_gather spends here.
+// One level of a descent: the block's records as this lane holds them (records lane, lane + 64, ...).
+template <class GT>
+struct Lvl {
+  static constexpr int NI = (GT::A + 63) / 64;
+  float p[NI];
+  uint32_t act[NI];
+  int2 nm[NI];
+  double q[NI];
+};
 template <class GT>
 struct SelPre {
   static constexpr int RW = (8 * GT::SW + 63) / 64;  // ring words per lane
   bool active;
-  int ply, player, used, rootN;
+  int ply, player, used, rootN, rootV;
   uint32_t rw[RW], cw;
 };
 template <class GT>
@@ -209,10 +257,126 @@ __device__ __forceinline__ void sel_load_ring(const View &v, const int g, const 
   s.cw = lane < GT::SW ? tb[(size_t)s.ply * GT::SW + lane] : 0u;
 }
 
+// A node's block is read with ALL its loads in flight at once (indices past the block are clamped to its last record and
+// ignored), so a tree level costs one memory round trip: the light part of every record, the heavy part of the first
+// `vt` (touched) ones only.
+template <class GT>
+__device__ __forceinline__ void lvl_fetch(const View &v, const size_t eb, const int base, const int cnt, const int vt, const int lane,
+                                          Lvl<GT> &L) {
+  // (wave-uniform block pointers + a 32-bit lane index: scalar base / vector offset addressing, no 64-bit lane arithmetic)
+  const float *P = v.edgeP + eb + base;
+  const uint8_t *Ac = v.edgeAct + eb + base;
+  const int2 *NM = v.edgeNM + eb + base;
+  const double *Q = v.edgeQ + eb + base;
+#pragma unroll
+  for (int k = 0; k < Lvl<GT>::NI; ++k) {
+    const int i = lane + 64 * k;
+    const uint32_t ic = (uint32_t)min(i, cnt - 1);
+    L.p[k] = P[ic];
+    L.act[k] = Ac[ic];
+    if (i < vt) { L.nm[k] = NM[ic]; L.q[k] = Q[ic]; }
+    else { L.nm[k] = make_int2(0, 0); L.q[k] = 0.0; }
+  }
+}
+struct Pick { int pos, act, n; uint32_t meta; };
+// MCTSNode.select :59-78 over one block.  `queued(pos)`: descents of the running wave step already queued through the
+// record (virtual loss, wave mode only).  Ties: the reference keeps the first maximum of its loop over ascending
+// actions, i.e. the lowest action; records are not in action order here, so the action is part of the comparison key.
+// The argmax runs on ONE 64-bit key per candidate -- {order-preserving image of the f32 score | ~(action, position)} --
+// so a butterfly round is two lane exchanges and one compare; the winner's visits and meta word are read from the lane
+// that holds them afterwards.  (Scores are never -0.0 -- a sum that cancels rounds to +0.0 -- and "+ 0.0f" makes sure;
+// a NaN score, which `>` never selects in the reference, maps to key 0 = no candidate.)
+template <class GT, bool WAVE, class QF>
+__device__ __forceinline__ Pick lvl_pick(const View &v, const Lvl<GT> &L, const int cnt, const int vt, const int nParent, const int lane,
+                                         QF queued) {
+  // f32(sqrt64(N)) of the reference == the correctly rounded sqrtf(N) (N < 2^24; 53 >= 2 * 24 + 2 bits make the double
+  // rounding harmless), which is what this file is compiled to
+  const float sqrtN = sqrtf((float)nParent);
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int k = 0; k < Lvl<GT>::NI; ++k) {
+    const int i = lane + 64 * k;
+    float sc;
+    if (64 * k >= vt) {
+      // every record this slot holds is untouched (wave-uniform test): visits 0, value +-0.0, no queued descent, so the
+      // score is (c * P) * sqrt(N) / 1 + (+-0) = (c * P) * sqrt(N) exactly -- no divide, no f64
+      sc = (v.c_puct * L.p[k]) * sqrtN;
+    } else {
+      const int n = L.nm[k].x;
+      const double q0 = n > 0 ? L.q[k] : 0.0;  // untouched / unvisited: child.value is still its initial 0.0
+      double qs = ((uint32_t)L.nm[k].y & META_SAME) ? q0 : -q0;
+      if (WAVE) qs = qs - (v.vl * (double)queued(i)) / (double)(n + 1);  // core/MCTS_alphazero.py:70
+      const float u = ((v.c_puct * L.p[k]) * sqrtN) / (float)(n + 1);
+      sc = (float)qs + u;
+    }
+    sc = sc + 0.0f;
+    const uint32_t b = __float_as_uint(sc);
+    const uint32_t mono = b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);  // unsigned order == float order
+    const uint32_t key = ~((L.act[k] << 16) | (uint32_t)i);                    // larger == lower action
+    const unsigned long long cand = (i < cnt && sc == sc) ? (((unsigned long long)mono << 32) | key) : 0ull;
+    best = cand > best ? cand : best;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), off, 64), lo = (uint32_t)__shfl_xor((int)(uint32_t)best, off, 64);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    best = o > best ? o : best;
+  }
+  const uint32_t hiw = (uint32_t)uni((int)(uint32_t)(best >> 32)), key = ~(uint32_t)uni((int)(uint32_t)best);
+  Pick w;
+  if (hiw == 0u) { w.pos = 0x7fffffff; w.act = 0; w.n = 0; w.meta = 0; return w; }  // no candidate
+  w.pos = (int)(key & 0xFFFFu);
+  w.act = (int)(key >> 16);
+  int n = L.nm[0].x, m = L.nm[0].y;  // the winner's heavy words, from the lane and slot that hold them (zeros if untouched)
+#pragma unroll
+  for (int k = 1; k < Lvl<GT>::NI; ++k) { n = (w.pos >> 6) == k ? L.nm[k].x : n; m = (w.pos >> 6) == k ? L.nm[k].y : m; }
+  w.n = __builtin_amdgcn_readlane(n, w.pos & 63);
+  w.meta = (uint32_t)__builtin_amdgcn_readlane(m, w.pos & 63);
+  return w;
+}
+template <class GT>
+__device__ __forceinline__ float lvl_take_f(const float (&x)[Lvl<GT>::NI], int slot, int srcLane) {
+  float r = x[0];
+#pragma unroll
+  for (int k = 1; k < Lvl<GT>::NI; ++k) r = slot == k ? x[k] : r;
+  return __shfl(r, srcLane, 64);
+}
+template <class GT>
+__device__ __forceinline__ uint32_t lvl_take_u(const uint32_t (&x)[Lvl<GT>::NI], int slot, int srcLane) {
+  uint32_t r = x[0];
+#pragma unroll
+  for (int k = 1; k < Lvl<GT>::NI; ++k) r = slot == k ? x[k] : r;
+  return (uint32_t)__shfl((int)r, srcLane, 64);
+}
+// First touch of record `pos` (>= vt) of the block at `base`: it changes places with record vt, gets its heavy part
+// {0 visits, same-player flag, no block yet, value 0.0}, and the block's touched count -- kept beside the pointer to the
+// block: the parent record's meta, or rootV -- goes up by one.  L still holds the block as fetched.
+template <class GT>
+__device__ __forceinline__ void lvl_touch(const View &v, const size_t eb, const int base, const int vt, const Pick &w, const bool same,
+                                          const Lvl<GT> &L, const int lane, const int parentEdge, const uint32_t parentMeta, const int g) {
+  const float pv = lvl_take_f<GT>(L.p, vt >> 6, vt & 63), pw = lvl_take_f<GT>(L.p, w.pos >> 6, w.pos & 63);
+  const uint32_t av = lvl_take_u<GT>(L.act, vt >> 6, vt & 63);
+  if (lane == 0) {
+    const size_t et = eb + base + vt, ep = eb + base + w.pos;
+    if (w.pos != vt) {
+      v.edgeP[ep] = pv; v.edgeAct[ep] = (uint8_t)av;
+      v.edgeP[et] = pw; v.edgeAct[et] = (uint8_t)w.act;
+    }
+    v.edgeNM[et] = make_int2(0, same ? (int)META_SAME : 0);
+    v.edgeQ[et] = 0.0;
+    if (parentEdge >= 0) v.edgeNM[eb + parentEdge].y = (int)(parentMeta + 1u);
+    else v.rootV[g] = vt + 1;
+  }
+}
+
 template <class GT, typename OutT>
-__device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input, const int g, const int lane, const SelPre<GT> &s) {
-  __shared__ uint32_t hist[8][GT::SW];
-  __shared__ uint32_t cur[GT::SW];
+__device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input, const int g, const int lane, const SelPre<GT> &s,
+                                                   const int wid, StatAcc &sa) {
+  __shared__ uint32_t histAll[TREE_WPB][8][GT::SW];
+  __shared__ uint32_t curAll[TREE_WPB][GT::SW];
+  uint32_t(*hist)[GT::SW] = histAll[wid];
+  uint32_t *cur = curAll[wid];
+  static_assert(GT::A <= 256, "edgeAct holds the action in one byte");
   const bool slotActive = s.active;
   const int ply = s.ply;
   int pl = s.player;
@@ -221,78 +385,51 @@ __device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input
   if (!slotActive) { if (lane == 0) v.evalFlag[g] = 0; return; }
   const size_t eb = (size_t)g * v.E;
 
-  // A node's block is read with ALL its loads in flight at once (a lane owns records lane, lane + 64, ...; indices past
-  // the block are clamped to its last record and ignored), so a tree level costs one memory round trip; the root's block
-  // is requested before the history ring is staged, so that it travels together with the ring and the board.
-  constexpr int NI = (GT::A + 63) / 64;
-  double eq[NI];
-  int2 epn[NI];
-  uint32_t em[NI];
-  auto fetch = [&](int base, int cnt) {
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const int i = min(lane + 64 * k, cnt - 1);
-      const size_t e = eb + base + i;
-      eq[k] = v.edgeQ[e];
-      epn[k] = v.edgePN[e];
-      em[k] = v.edgeMeta[e];
-    }
-  };
+  // the root's block is requested before the history ring is staged, so that it travels together with the ring and the board
+  Lvl<GT> L;
   constexpr int RW = SelPre<GT>::RW;
-  if (used > 0) fetch(0, GT::PMAX - ply);
+  int vt = s.rootV;
+  if (used > 0) lvl_fetch<GT>(v, eb, 0, GT::PMAX - ply, vt, lane, L);
 #pragma unroll
   for (int k = 0; k < RW; ++k) {
     const int i = lane + 64 * k;
     if (i < 8 * GT::SW) hist[i / GT::SW][i % GT::SW] = s.rw[k];
   }
   if (lane < GT::SW) cur[lane] = s.cw;
-  __syncthreads();
+  wave_sync();
 
-  int head = 0, depth = 0, kind = KIND_EVAL, base = 0;
+  int head = 0, depth = 0, kind = KIND_EVAL, base = 0, parentEdge = -1;
+  uint32_t parentMeta = 0;
   float tval = 0.0f;
-  unsigned long long scanned = 0;
+  unsigned long long scanned = 0, scannedTouched = 0;
   if (used > 0) {
     for (;;) {
       if (depth >= v.D) { if (lane == 0) atomicOr(v.err, ERR_DEPTH_CAP); return; }
       const int cnt = GT::PMAX - (ply + depth);  // legal actions of a non-terminal position
-      const float sqrtN = (float)sqrt((double)nParent);
-      float best = -INFINITY;
-      int bestIdx = 0x7fffffff, bestN = 0;
-      uint32_t bestMeta = 0;
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        const int i = lane + 64 * k;
-        const double q0 = epn[k].y > 0 ? eq[k] : 0.0;  // unvisited: child.value is still its initial 0.0 (never stored)
-        const double qs = (em[k] & META_SAME) ? q0 : -q0;
-        const float u = ((v.c_puct * __int_as_float(epn[k].x)) * sqrtN) / (float)(epn[k].y + 1);
-        const float sc = (float)qs + u;
-        if (i < cnt && sc > best) { best = sc; bestIdx = i; bestMeta = em[k]; bestN = epn[k].y; }
-      }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        const float ob = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bestIdx, off, 64);
-        const uint32_t om = (uint32_t)__shfl_xor((int)bestMeta, off, 64);
-        const int on = __shfl_xor(bestN, off, 64);
-        if (ob > best || (ob == best && oi < bestIdx)) { best = ob; bestIdx = oi; bestMeta = om; bestN = on; }
-      }
-      bestIdx = uni(bestIdx);
-      const uint32_t meta = (uint32_t)uni((int)bestMeta);
-      const int nEdge = uni(bestN);
+      const Pick w = lvl_pick<GT, false>(v, L, cnt, vt, nParent, lane, [](int) { return 0; });
       scanned += (unsigned)cnt;
-      if (bestIdx >= cnt) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
-      const int a = (int)(meta & META_ACT);
-      const int kid = (int)(meta >> META_KID_SHIFT);
-      if (kid) fetch(kid - 1, cnt - 1);  // the child's block: on its way while the move is replayed on the board
-      if (lane == 0) v.path[(size_t)g * v.D + depth] = base + bestIdx;
+      scannedTouched += (unsigned)vt;
+      if (w.pos >= cnt) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
+      const int kid = (int)(w.meta >> META_KID_SHIFT);
+      const bool touched = w.pos < vt;
+      // the child's block: on its way while the move is replayed on the board.  (An untouched record has no block yet, so
+      // the registers the touch below reads -- the block as fetched -- are never the ones this fetch overwrites.)
+      if (kid) lvl_fetch<GT>(v, eb, kid - 1, cnt - 1, (int)(w.meta & META_V), lane, L);
+      const int edge = base + (touched ? w.pos : vt);
+      if (lane == 0) v.path[(size_t)g * v.D + depth] = edge;
       ++depth;
       const int mover = pl;
-      pl = GT::apply(cur, a, mover, lane);
+      pl = GT::apply(cur, w.act, mover, lane);
       if (lane < GT::SW) hist[head][lane] = cur[lane];
       head = (head + 1) & 7;
-      __syncthreads();
-      if (kid) { base = kid - 1; nParent = nEdge; continue; }
-      const int term = uni(GT::terminal(cur, a, mover, ply + depth, lane));
+      wave_sync();
+      if (!touched) lvl_touch<GT>(v, eb, base, vt, w, pl == mover, L, lane, parentEdge, parentMeta, g);
+      if (kid) {
+        parentEdge = edge; parentMeta = w.meta;
+        base = kid - 1; vt = (int)(w.meta & META_V); nParent = w.n;
+        continue;
+      }
+      const int term = uni(GT::terminal(cur, w.act, mover, ply + depth, lane));
       if (term != T_NONE) { kind = KIND_TERMINAL; tval = terminal_value(term, pl); }
       break;
     }
@@ -300,10 +437,8 @@ __device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input
   if (lane == 0) {
     v.leaf[g] = make_int4(depth, kind, (int)__float_as_uint(tval), pl);
     v.evalFlag[g] = kind == KIND_EVAL;
-    unsigned long long *st = v.stat + (size_t)g * 6;
-    st[0] += 1; st[1] += (unsigned)depth; st[2] += scanned;
-    st[3] += (kind == KIND_EVAL); st[4] += (kind == KIND_TERMINAL);
   }
+  sa.add(lane, 1, (unsigned)depth, scanned, kind == KIND_EVAL, kind == KIND_TERMINAL, 0, scannedTouched);
   if (kind == KIND_EVAL) {
     uint32_t *lr = v.leafRing + (size_t)g * 8 * GT::SW;
     for (int i = lane; i < 8 * GT::SW; i += 64) lr[i] = hist[(head + i / GT::SW) & 7][i % GT::SW];
@@ -312,16 +447,21 @@ __device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input
 }
 
 template <class GT, typename OutT>
-__global__ __launch_bounds__(64) void k_select_gather(View v, OutT *nn_input) {
-  const int g = blockIdx.x, lane = threadIdx.x;
+__global__ AZ_TREE_BOUNDS void k_select_gather(View v, OutT *nn_input) {
+  const int wid = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, g = blockIdx.x * TREE_WPB + wid;  // (wid in an SGPR: everything indexed by g stays scalar)
+  if (g >= v.G) return;  // (no workgroup barrier anywhere below: a wave may leave early)
   SelPre<GT> s;
+  StatAcc sa;
+  sa.load(v.stat + (size_t)g * NSTAT, lane);
   s.active = v.active[g] != 0;  // one batch
   s.ply = v.ply[g];
   s.player = v.player[g];
   s.used = v.edgeCnt[g];
   s.rootN = v.rootN[g];
+  s.rootV = v.rootV[g];
   sel_load_ring<GT>(v, g, lane, s);  // (all valid memory for an inactive slot too)
-  select_gather_body<GT, OutT>(v, nn_input, g, lane, s);
+  select_gather_body<GT, OutT>(v, nn_input, g, lane, s, wid, sa);
+  sa.store();
 }
 
 // Compact list of the slots whose leaf needs the network, in slot order: one workgroup; each thread owns a
@@ -367,9 +507,11 @@ struct WaveCarry { int used, rootN; double rootQ; };
 
 template <class GT, bool PRE>
 __device__ __forceinline__ void expand_backup_body(const View &v, const float *logits, const float *values, const float *noise,
-                                                   const int g, const int lane, SelPre<GT> *sp, const int vs, WaveCarry *wc) {
+                                                   const int g, const int lane, SelPre<GT> *sp, const int vs, WaveCarry *wc,
+                                                   const int wid, StatAcc &sa) {
   const bool slotActive = v.active[g] != 0;  // tested after the batch below is on its way (all of it is valid memory)
-  __shared__ uint32_t st[GT::SW];
+  __shared__ uint32_t stAll[TREE_WPB][GT::SW];
+  uint32_t *st = stAll[wid];
   constexpr int A = GT::A, NI = (A + 63) / 64;
   const size_t eb = (size_t)g * v.E;
   const int32_t *path = v.path + (size_t)vs * v.D;
@@ -382,7 +524,7 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int a = lane + 64 * i;
-    p[i] = logits[(size_t)vs * A + min(a, A - 1)];
+    p[i] = (logits + (size_t)vs * A)[(uint32_t)min(a, A - 1)];  // (uniform row pointer + 32-bit lane offset, here and below)
   }
   const float nnv = values[vs];
   const int used = wc ? wc->used : v.edgeCnt[g];
@@ -395,24 +537,29 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
     sp->player = v.player[g];
     sp->used = used;    // (what the descent finds if this body leaves early on an error)
     sp->rootN = rootN;
+    sp->rootV = v.rootV[g];  // (0 right after the root's own expansion: k_begin_search cleared it)
   }
   if (!slotActive) return;
+  const int depth = uni(lf.x), kind = uni(lf.y);
+  // (Tried: requesting the root's block here too, one round trip ahead of the descent that needs it, and patching the one
+  // record the backup rewrites -- 35.6 -> 49.6 us per launch, with or without the spills it caused: not kept.)
   if (PRE) sel_load_ring<GT>(v, g, lane, *sp);  // on its way with the path records below
-  const int depth = lf.x, kind = lf.y;
   // this lane's path edge (lane j owns path edge depth-1-j), fetched before the expansion's arithmetic
   const int pj = depth <= 64 ? __shfl(pth, max(depth - 1 - lane, 0), 64) : path[depth - 1 - lane];
   const bool onPath = lane < depth;
-  const size_t pe = eb + (onPath ? pj : 0);
-  uint32_t pmeta = 0;
-  int2 ppn = make_int2(0, 0);
+  const uint32_t pe = (uint32_t)(onPath ? pj : 0);  // index into this tree's record arrays
+  int2 *const tNM = v.edgeNM + eb;
+  double *const tQ = v.edgeQ + eb;
+  int2 pnm = make_int2(0, 0);  // {visits, meta}: a path record has been touched, so its heavy part exists
   double pq = 0.0;
-  if (onPath) { pmeta = v.edgeMeta[pe]; ppn = v.edgePN[pe]; pq = v.edgeQ[pe]; }
-  if (ppn.y == 0) pq = 0.0;  // first visit: the stored bytes are not a value yet
+  if (onPath) { pnm = tNM[pe]; pq = tQ[pe]; }
+  const uint32_t pmeta = (uint32_t)pnm.y;
+  if (pnm.x == 0) pq = 0.0;  // first visit (the touch wrote 0.0 anyway)
 
   double val;
   if (kind == KIND_EVAL) {
     if (lane < GT::SW) st[lane] = bw;
-    __syncthreads();
+    wave_sync();
     bool lg[NI];
     float mx = -INFINITY;
 #pragma unroll
@@ -435,7 +582,7 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
     float nz[NI];
     if (mix) {  // wave-uniform: the Dirichlet row, all of it in one batch
 #pragma unroll
-      for (int i = 0; i < NI; ++i) nz[i] = noise[(size_t)g * A + min(lane + 64 * i, A - 1)];
+      for (int i = 0; i < NI; ++i) nz[i] = (noise + (size_t)g * A)[(uint32_t)min(lane + 64 * i, A - 1)];
     }
     acc = 0.0f;
 #pragma unroll
@@ -459,10 +606,9 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
     for (int i = 0; i < NI; ++i) {
       const int a = lane + 64 * i;
       if (lg[i]) {
-        const int pos = off + __popcll(bal[i] & ((1ull << lane) - 1ull));
-        const size_t e = eb + used + pos;
-        v.edgePN[e] = make_int2(__float_as_int(p[i] / tot), 0);
-        v.edgeMeta[e] = (uint32_t)a | (GT::same_player(st, a) ? META_SAME : 0u);
+        const uint32_t pos = (uint32_t)(off + __popcll(bal[i] & ((1ull << lane) - 1ull)));
+        (v.edgeP + eb + used)[pos] = p[i] / tot;  // the light part only: 5 B per child; the heavy part waits for the child's first touch
+        (v.edgeAct + eb + used)[pos] = (uint8_t)a;
       }
       off += __popcll(bal[i]);
     }
@@ -471,9 +617,9 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
     if (lane == 0) {
       v.edgeCnt[g] = used + nLegal;
       // the leaf's own edge is path[depth-1] = lane 0's path edge: link it to its new block
-      if (depth > 0) v.edgeMeta[pe] = pmeta | ((uint32_t)(used + 1) << META_KID_SHIFT);
-      v.stat[(size_t)g * 6 + 5] += (unsigned)nLegal;
+      if (depth > 0) tNM[pe].y = (int)(pmeta | ((uint32_t)(used + 1) << META_KID_SHIFT));
     }
+    sa.add(lane, 0, 0, 0, 0, 0, (unsigned)nLegal, 0);
     val = (double)nnv;  // value.item()
   } else {
     val = (double)__uint_as_float((uint32_t)lf.z);
@@ -483,12 +629,13 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
   {
     const bool flip = onPath && (pmeta & META_SAME) == 0u;
     const unsigned long long fm = __ballot(flip);
+    const int below = __popcll(fm & ((1ull << lane) - 1ull));
+    const double x = (below & 1) ? -val : val;
+    const int n = pnm.x + 1;
+    const double qNew = pq + (x - pq) / (double)n;
     if (onPath) {
-      const int below = __popcll(fm & ((1ull << lane) - 1ull));
-      const double x = (below & 1) ? -val : val;
-      const int n = ppn.y + 1;
-      v.edgePN[pe].y = n;
-      v.edgeQ[pe] = pq + (x - pq) / (double)n;
+      tNM[pe].x = n;
+      tQ[pe] = qNew;
     }
     if (__popcll(fm) & 1) val = -val;
   }
@@ -498,13 +645,13 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
     size_t e = 0;
     if (j < depth) {
       e = eb + path[depth - 1 - j];
-      flip = (v.edgeMeta[e] & META_SAME) == 0u;
+      flip = ((uint32_t)v.edgeNM[e].y & META_SAME) == 0u;
     }
     const unsigned long long fm = __ballot(flip);
     if (j < depth) {
       const int below = __popcll(fm & ((1ull << lane) - 1ull));
       const double x = (below & 1) ? -val : val;
-      int *np = &v.edgePN[e].y;
+      int *np = &v.edgeNM[e].x;
       const int n = *np + 1;
       const double q = n > 1 ? v.edgeQ[e] : 0.0;
       *np = n;
@@ -522,9 +669,14 @@ __device__ __forceinline__ void expand_backup_body(const View &v, const float *l
 }
 
 template <class GT>
-__global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logits, const float *values,
-                                                      const float *noise) {
-  expand_backup_body<GT, false>(v, logits, values, noise, blockIdx.x, threadIdx.x, nullptr, blockIdx.x, nullptr);
+__global__ AZ_TREE_BOUNDS void k_expand_backup(View v, const float *logits, const float *values,
+                                                                 const float *noise) {
+  const int wid = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, g = blockIdx.x * TREE_WPB + wid;  // (wid in an SGPR: everything indexed by g stays scalar)
+  if (g >= v.G) return;
+  StatAcc sa;
+  sa.load(v.stat + (size_t)g * NSTAT, lane);
+  expand_backup_body<GT, false>(v, logits, values, noise, g, lane, nullptr, g, nullptr, wid, sa);
+  sa.store();
 }
 
 // ------------------------------------------------------------------------- wave search --------
@@ -538,93 +690,65 @@ __global__ __launch_bounds__(64) void k_expand_backup(View v, const float *logit
 // and backed up in queue order.  K = 1 is the sequential search, bit for bit.
 template <class GT, typename OutT>
 __global__ __launch_bounds__(64) void k_select_wave(View v, OutT *nn_input, int target) {
-  constexpr int DL = GT::PMAX + 1, NI = (GT::A + 63) / 64, RW = SelPre<GT>::RW;
+  constexpr int DL = GT::PMAX + 1, RW = SelPre<GT>::RW;
   __shared__ uint32_t hist[8][GT::SW];
   __shared__ uint32_t cur[GT::SW];
   __shared__ int32_t wp[WAVE_KMAX][DL];  // the queued descents' paths: edge followed at each level
   __shared__ int32_t wlen[WAVE_KMAX];
   const int g = blockIdx.x, lane = threadIdx.x, K = v.K;
   SelPre<GT> s;
+  StatAcc sa;
+  sa.load(v.stat + (size_t)g * NSTAT, lane);
   s.active = v.active[g] != 0;
   s.ply = v.ply[g];
   s.player = v.player[g];
   s.used = v.edgeCnt[g];
   s.rootN = v.rootN[g];
+  s.rootV = v.rootV[g];
   sel_load_ring<GT>(v, g, lane, s);
   if (lane < K) v.evalFlag[(size_t)g * K + lane] = 0;
   const int budget = s.active ? min(K, target - s.rootN) : 0;
   if (budget <= 0) { if (lane == 0) v.waveCnt[g] = 0; return; }
   const int ply = s.ply, used = s.used;
   const size_t eb = (size_t)g * v.E;
-  double eq[NI];
-  int2 epn[NI];
-  uint32_t em[NI];
-  auto fetch = [&](int base, int cnt) {
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const int i = min(lane + 64 * k, cnt - 1);
-      const size_t e = eb + base + i;
-      eq[k] = v.edgeQ[e];
-      epn[k] = v.edgePN[e];
-      em[k] = v.edgeMeta[e];
-    }
-  };
-  int nq = 0;
-  unsigned long long scanned = 0, sumDepth = 0;
+  Lvl<GT> L;
+  int nq = 0, rootV = s.rootV;  // (the root's touched count moves as this step's descents touch new children)
+  unsigned long long scanned = 0, scannedTouched = 0, sumDepth = 0;
   int nEval = 0, nTerm = 0;
   for (int j = 0; j < budget; ++j) {
-    __syncthreads();  // the previous descent is done with hist / cur
-    if (used > 0) fetch(0, GT::PMAX - ply);
+    wave_sync();  // the previous descent is done with hist / cur, and its record swaps are ordered before this descent's loads
+    int vt = rootV;
+    if (used > 0) lvl_fetch<GT>(v, eb, 0, GT::PMAX - ply, vt, lane, L);
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
       const int i = lane + 64 * k;
       if (i < 8 * GT::SW) hist[i / GT::SW][i % GT::SW] = s.rw[k];
     }
     if (lane < GT::SW) cur[lane] = s.cw;
-    __syncthreads();
+    wave_sync();
     uint32_t share = (1u << nq) - 1u;  // queued descents that followed the same edges so far
-    int head = 0, depth = 0, kind = KIND_EVAL, base = 0, pl = s.player, nParent = s.rootN;
+    int head = 0, depth = 0, kind = KIND_EVAL, base = 0, pl = s.player, nParent = s.rootN, parentEdge = -1;
+    uint32_t parentMeta = 0;
     float tval = 0.0f;
     if (used > 0) {
       for (;;) {
         if (depth >= v.D || depth >= DL) { if (lane == 0) atomicOr(v.err, ERR_DEPTH_CAP); return; }
         const int cnt = GT::PMAX - (ply + depth);
-        const float sqrtN = (float)sqrt((double)nParent);
-        float best = -INFINITY;
-        int bestIdx = 0x7fffffff, bestN = 0;
-        uint32_t bestMeta = 0;
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-          const int i = lane + 64 * k;
-          int c = 0;  // queued descents through this child
+        const Pick w = lvl_pick<GT, true>(v, L, cnt, vt, nParent, lane, [&](int i) {
+          int c = 0;  // queued descents through this child (queued paths only hold touched records, whose positions are final)
           for (uint32_t m = share; m; m &= m - 1u) {
             const int p = __ffs((int)m) - 1;
             c += (wlen[p] > depth && wp[p][depth] == base + i) ? 1 : 0;
           }
-          const double q0 = epn[k].y > 0 ? eq[k] : 0.0;
-          double qs = (em[k] & META_SAME) ? q0 : -q0;
-          qs = qs - (v.vl * (double)c) / (double)(epn[k].y + 1);  // core/MCTS_alphazero.py:70
-          const float u = ((v.c_puct * __int_as_float(epn[k].x)) * sqrtN) / (float)(epn[k].y + 1);
-          const float sc = (float)qs + u;
-          if (i < cnt && sc > best) { best = sc; bestIdx = i; bestMeta = em[k]; bestN = epn[k].y; }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          const float ob = __shfl_xor(best, off, 64);
-          const int oi = __shfl_xor(bestIdx, off, 64);
-          const uint32_t om = (uint32_t)__shfl_xor((int)bestMeta, off, 64);
-          const int on = __shfl_xor(bestN, off, 64);
-          if (ob > best || (ob == best && oi < bestIdx)) { best = ob; bestIdx = oi; bestMeta = om; bestN = on; }
-        }
-        bestIdx = uni(bestIdx);
-        const uint32_t meta = (uint32_t)uni((int)bestMeta);
-        const int nEdge = uni(bestN);
+          return c;
+        });
         scanned += (unsigned)cnt;
-        if (bestIdx >= cnt) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
-        const int a = (int)(meta & META_ACT);
-        const int kid = (int)(meta >> META_KID_SHIFT);
-        if (kid) fetch(kid - 1, cnt - 1);
-        const int edge = base + bestIdx;
+        scannedTouched += (unsigned)vt;
+        if (w.pos >= cnt) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
+        const int kid = (int)(w.meta >> META_KID_SHIFT);
+        const bool touched = w.pos < vt;
+        if (kid) lvl_fetch<GT>(v, eb, kid - 1, cnt - 1, (int)(w.meta & META_V), lane, L);  // (never together with the touch below)
+        const int edge = base + (touched ? w.pos : vt);
         uint32_t ns = 0;
         for (uint32_t m = share; m; m &= m - 1u) {
           const int p = __ffs((int)m) - 1;
@@ -634,12 +758,20 @@ __global__ __launch_bounds__(64) void k_select_wave(View v, OutT *nn_input, int 
         if (lane == 0) wp[nq][depth] = edge;
         ++depth;
         const int mover = pl;
-        pl = GT::apply(cur, a, mover, lane);
+        pl = GT::apply(cur, w.act, mover, lane);
         if (lane < GT::SW) hist[head][lane] = cur[lane];
         head = (head + 1) & 7;
-        __syncthreads();
-        if (kid) { base = kid - 1; nParent = nEdge; continue; }
-        const int term = uni(GT::terminal(cur, a, mover, ply + depth, lane));
+        wave_sync();
+        if (!touched) {
+          lvl_touch<GT>(v, eb, base, vt, w, pl == mover, L, lane, parentEdge, parentMeta, g);
+          if (parentEdge < 0) rootV = vt + 1;
+        }
+        if (kid) {
+          parentEdge = edge; parentMeta = w.meta;
+          base = kid - 1; vt = (int)(w.meta & META_V); nParent = w.n;
+          continue;
+        }
+        const int term = uni(GT::terminal(cur, w.act, mover, ply + depth, lane));
         if (term != T_NONE) { kind = KIND_TERMINAL; tval = terminal_value(term, pl); }
         break;
       }
@@ -667,9 +799,9 @@ __global__ __launch_bounds__(64) void k_select_wave(View v, OutT *nn_input, int 
   }
   if (lane == 0) {
     v.waveCnt[g] = nq;
-    unsigned long long *st = v.stat + (size_t)g * 6;
-    st[0] += (unsigned)nq; st[1] += sumDepth; st[2] += scanned; st[3] += (unsigned)nEval; st[4] += (unsigned)nTerm;
   }
+  sa.add(lane, (unsigned)nq, sumDepth, scanned, (unsigned)nEval, (unsigned)nTerm, 0, scannedTouched);
+  sa.store();
 }
 
 template <class GT>
@@ -678,11 +810,14 @@ __global__ __launch_bounds__(64) void k_expand_wave(View v, const float *logits,
   const int cnt = v.waveCnt[g];
   WaveCarry wc{v.edgeCnt[g], v.rootN[g], v.rootQ[g]};
   if (!v.active[g] || cnt <= 0) return;
+  StatAcc sa;
+  sa.load(v.stat + (size_t)g * NSTAT, lane);
   for (int j = 0; j < cnt; ++j) {
-    expand_backup_body<GT, false>(v, logits, values, noise, g, lane, nullptr, g * v.K + j, &wc);
-    __syncthreads();  // the next leaf's path may share edges this one has just updated; `st` is reused
+    expand_backup_body<GT, false>(v, logits, values, noise, g, lane, nullptr, g * v.K + j, &wc, 0, sa);
+    wave_sync();  // the next leaf's path may share edges this one has just updated; `st` is reused
   }
   if (lane == 0) v.waveCnt[g] = 0;
+  sa.store();
 }
 
 // simulations still to run for a search of `target` simulations: {sum over active trees, max} (az_search_remaining)
@@ -710,14 +845,43 @@ __global__ __launch_bounds__(256) void k_search_remaining(View v, int target) {
 // alternates network <-> tree, so this halves the tree launches and their dispatch gaps).  The descent re-reads
 // records the backup has just written -- by the same wavefront, through the same L1: a workgroup-scope fence (what
 // __syncthreads() carries) orders them.  (An agent-scope __threadfence() here writes back the L2 once per wave: 590 us.)
+#ifdef AZ_TREE_STAMP  // diagnostic build: when every wave of k_expand_select started and ended (scripts/dev/tree_stamp.py)
+__device__ unsigned long long g_tree_stamp[65536][3];  // {start, end} in 100 MHz ticks, {XCC | SE | CU ids}
+#endif
+
 template <class GT, typename OutT>
-__global__ __launch_bounds__(64) void k_expand_select(View v, const float *logits, const float *values, const float *noise,
-                                                      OutT *nn_input) {
+__global__ AZ_TREE_BOUNDS void k_expand_select(View v, const float *logits, const float *values, const float *noise,
+                                                                 OutT *nn_input) {
+  const int wid = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, g = blockIdx.x * TREE_WPB + wid;  // (wid in an SGPR: everything indexed by g stays scalar)
+  if (g >= v.G) return;
+#ifdef AZ_TREE_STAMP
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
   SelPre<GT> s;
-  expand_backup_body<GT, true>(v, logits, values, noise, blockIdx.x, threadIdx.x, &s, blockIdx.x, nullptr);
-  __syncthreads();
-  select_gather_body<GT, OutT>(v, nn_input, blockIdx.x, threadIdx.x, s);
+  StatAcc sa;
+  sa.load(v.stat + (size_t)g * NSTAT, lane);
+  expand_backup_body<GT, true>(v, logits, values, noise, g, lane, &s, g, nullptr, wid, sa);
+  wave_sync();
+  select_gather_body<GT, OutT>(v, nn_input, g, lane, s, wid, sa);
+  sa.store();
+#ifdef AZ_TREE_STAMP
+  if (lane == 0 && g < 65536) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_tree_stamp[g][0] = t_start;
+    g_tree_stamp[g][1] = __builtin_amdgcn_s_memrealtime();
+    g_tree_stamp[g][2] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
+
+#ifdef AZ_TREE_STAMP
+extern "C" int az_tree_stamps(unsigned long long *out_host, int n) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_tree_stamp), sizeof(unsigned long long) * 3 * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ------------------------------------------------------------------------- root policy --------
 template <class GT>
@@ -730,12 +894,13 @@ __global__ __launch_bounds__(64) void k_root_policy(View v, float *pi, int32_t *
   const bool have = v.active[g] && v.edgeCnt[g] > 0;
   const size_t eb = (size_t)g * v.E;
   float tot = 1.0f;
+  const int vt = have ? v.rootV[g] : 0;  // records [0, vt) of the root's block have been touched: only they hold visits
   if (have) {
     const int cnt = GT::PMAX - v.ply[g];
     int s = 0;
     for (int i = lane; i < cnt; i += 64) {
-      s += v.edgePN[eb + i].y;
-      edgeOf[v.edgeMeta[eb + i] & META_ACT] = i + 1;
+      if (i < vt) s += v.edgeNM[eb + i].x;
+      edgeOf[v.edgeAct[eb + i]] = i + 1;
     }
     tot = (float)wave_sum_i(s);
   }
@@ -744,11 +909,11 @@ __global__ __launch_bounds__(64) void k_root_policy(View v, float *pi, int32_t *
     const int k = edgeOf[a];
     const size_t e = eb + (k > 0 ? k - 1 : 0);
     const size_t o = (size_t)g * A + a;
-    const int2 pn = k ? v.edgePN[e] : make_int2(0, 0);
-    if (pi) pi[o] = k ? (float)pn.y / tot : 0.0f;
-    if (visits) visits[o] = pn.y;
-    if (childQ) childQ[o] = (k && pn.y > 0) ? v.edgeQ[e] : 0.0;
-    if (rootPrior) rootPrior[o] = __int_as_float(pn.x);
+    const int n = (k && k - 1 < vt) ? v.edgeNM[e].x : 0;
+    if (pi) pi[o] = k ? (float)n / tot : 0.0f;
+    if (visits) visits[o] = n;
+    if (childQ) childQ[o] = n > 0 ? v.edgeQ[e] : 0.0;
+    if (rootPrior) rootPrior[o] = k ? v.edgeP[e] : 0.0f;
   }
 }
 
@@ -784,18 +949,19 @@ __global__ __launch_bounds__(64) void k_play_moves(View v, const float *invTao, 
   if (v.edgeCnt[g] == 0 || ply >= GT::PMAX) { if (lane == 0) atomicOr(v.err, ERR_NO_ROOT); return; }
   const int cnt = GT::PMAX - ply;
   const size_t eb = (size_t)g * v.E;
+  const int vt = v.rootV[g];  // untouched root children have no visits: pi = 0, never sampled (w / expo = 0 loses to any visited child)
   int s = 0;
-  for (int i = lane; i < cnt; i += 64) s += v.edgePN[eb + i].y;
+  for (int i = lane; i < vt; i += 64) s += v.edgeNM[eb + i].x;
   const float tot = (float)wave_sum_i(s);
   const float it = invTao[g];
   float best = -INFINITY;
   int bestA = 0x7fffffff;
   for (int i = lane; i < cnt; i += 64) {
-    const int a = (int)(v.edgeMeta[eb + i] & META_ACT), n = v.edgePN[eb + i].y;
+    const int a = (int)v.edgeAct[eb + i], n = i < vt ? v.edgeNM[eb + i].x : 0;
     vis[a] = (uint16_t)n;
     const float pi = (float)n / tot;
     const float q = az_powf(pi, it) / expo[(size_t)g * A + a];
-    if (q > best) { best = q; bestA = a; }
+    if (q > best || (q == best && a < bestA)) { best = q; bestA = a; }  // (records are not in action order)
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -1011,6 +1177,7 @@ __global__ void k_reset_games(View v, const uint8_t *mask) {
   v.active[g] = 1;
   v.result[g] = 0.0f;
   v.edgeCnt[g] = 0;
+  v.rootV[g] = 0;
   v.rootN[g] = 0;
   v.rootQ[g] = 0.0;
   v.waveCnt[g] = 0;
@@ -1020,6 +1187,7 @@ __global__ void k_begin_search(View v) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= v.G) return;
   v.edgeCnt[g] = 0;
+  v.rootV[g] = 0;
   v.rootN[g] = 0;
   v.rootQ[g] = 0.0;
   v.waveCnt[g] = 0;
@@ -1215,9 +1383,11 @@ int az_create(const az_config *cfg, az_engine **out) {
     return p;
   };
   v.edgeQ = (double *)alloc(G * E * sizeof(double));
-  v.edgePN = (int2 *)alloc(G * E * sizeof(int2));
-  v.edgeMeta = (uint32_t *)alloc(G * E * sizeof(uint32_t));
+  v.edgeNM = (int2 *)alloc(G * E * sizeof(int2));
+  v.edgeP = (float *)alloc(G * E * sizeof(float));
+  v.edgeAct = (uint8_t *)alloc(G * E);
   v.edgeCnt = (int32_t *)alloc(G * sizeof(int32_t));
+  v.rootV = (int32_t *)alloc(G * sizeof(int32_t));
   v.rootN = (int32_t *)alloc(G * sizeof(int32_t));
   v.rootQ = (double *)alloc(G * sizeof(double));
   v.path = (int32_t *)alloc(GK * (size_t)d.depth_cap * sizeof(int32_t));
@@ -1237,7 +1407,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   v.player = (int32_t *)alloc(G * sizeof(int32_t));
   v.active = (uint8_t *)alloc(G);
   v.result = (float *)alloc(G * sizeof(float));
-  v.stat = (unsigned long long *)alloc(G * 6 * sizeof(unsigned long long));
+  v.stat = (unsigned long long *)alloc(G * NSTAT * sizeof(unsigned long long));
   v.err = (int32_t *)alloc(sizeof(int32_t));
   if (!ok) {
     g_create_err = "hipMalloc failed (engine needs " + std::to_string(total >> 20) + "+ MiB)";
@@ -1247,7 +1417,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   }
   d.device_bytes = total;
   // small state starts defined; the big pools need no clearing (bump allocated, written before read)
-  if (hipMemset(v.stat, 0, G * 6 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMemset(v.stat, 0, G * NSTAT * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(v.err, 0, sizeof(int32_t)) != hipSuccess || hipMemset(v.evalCount, 0, 64) != hipSuccess || hipMemset(v.evalFlag, 0, flag_bytes) != hipSuccess || hipMemset(v.active, 0, G) != hipSuccess ||
       hipMemset(v.ply, 0, G * sizeof(int32_t)) != hipSuccess || hipMemset(v.leaf, 0, GK * sizeof(int4)) != hipSuccess || hipMemset(v.waveCnt, 0, G * sizeof(int32_t)) != hipSuccess ||
       hipMemset(v.trajPlayer, 0, G * (size_t)(d.max_plies + 1)) != hipSuccess) {
@@ -1345,6 +1515,7 @@ int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32
   AZ_HIP(hipMemcpyAsync(e->v.player + slot, &one_player, sizeof(int32_t), hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.active + slot, &act, 1, hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.edgeCnt + slot, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  AZ_HIP(hipMemcpyAsync(e->v.rootV + slot, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.rootN + slot, &zero, sizeof(int32_t), hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.rootQ + slot, &zero_q, sizeof(double), hipMemcpyHostToDevice, s));
   AZ_HIP(hipMemcpyAsync(e->v.startPly + slot, &one_ply, sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -1375,7 +1546,7 @@ int az_select_gather(az_engine *e, void *nn_input_dev, void *stream) {
   if (!e) return AZ_EINVAL;
   if (e->v.K > 1) { e->err = "engine created with leaves_per_step > 1: use az_select_wave / az_expand_wave"; return AZ_EINVAL; }
   DeviceGuard guard(e->cfg.device);
-  const dim3 grid(e->v.G), block(64);
+  const dim3 grid((e->v.G + TREE_WPB - 1) / TREE_WPB), block(64 * TREE_WPB);
   hipStream_t s = (hipStream_t)stream;
   switch (e->cfg.nn_dtype) {
     case AZ_NN_F32: AZ_DISPATCH(e, hipLaunchKernelGGL((k_select_gather<GT, float>), grid, block, 0, s, e->v, (float *)nn_input_dev)); break;
@@ -1396,7 +1567,7 @@ int az_expand_backup(az_engine *e, const float *logits_dev, const float *values_
   if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
   if (e->v.K > 1) { e->err = "engine created with leaves_per_step > 1: use az_select_wave / az_expand_wave"; return AZ_EINVAL; }
   DeviceGuard guard(e->cfg.device);
-  AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_backup<GT>), dim3(e->v.G), dim3(64), 0, (hipStream_t)stream, e->v, logits_dev, values_dev, noise_dev));
+  AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_backup<GT>), dim3((e->v.G + TREE_WPB - 1) / TREE_WPB), dim3(64 * TREE_WPB), 0, (hipStream_t)stream, e->v, logits_dev, values_dev, noise_dev));
   return launch_check(e, "k_expand_backup");
 }
 
@@ -1405,7 +1576,7 @@ int az_expand_select(az_engine *e, const float *logits_dev, const float *values_
   if (!e || !logits_dev || !values_dev) return AZ_EINVAL;
   if (e->v.K > 1) { e->err = "engine created with leaves_per_step > 1: use az_select_wave / az_expand_wave"; return AZ_EINVAL; }
   DeviceGuard guard(e->cfg.device);
-  const dim3 grid(e->v.G), block(64);
+  const dim3 grid((e->v.G + TREE_WPB - 1) / TREE_WPB), block(64 * TREE_WPB);
   hipStream_t s = (hipStream_t)stream;
   switch (e->cfg.nn_dtype) {
     case AZ_NN_F32: AZ_DISPATCH(e, hipLaunchKernelGGL((k_expand_select<GT, float>), grid, block, 0, s, e->v, logits_dev, values_dev, noise_dev, (float *)nn_input_dev)); break;
@@ -1584,22 +1755,22 @@ int az_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t 
 int az_read_stats(az_engine *e, az_stats *out, void *stream) {
   if (!e || !out) return AZ_EINVAL;
   DeviceGuard guard(e->cfg.device);
-  const size_t n = (size_t)e->v.G * 6;
+  const size_t n = (size_t)e->v.G * NSTAT;
   std::vector<unsigned long long> h(n);
   AZ_HIP(hipMemcpyAsync(h.data(), e->v.stat, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
   AZ_HIP(hipStreamSynchronize((hipStream_t)stream));
-  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long acc[NSTAT] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (size_t g = 0; g < (size_t)e->v.G; ++g)
-    for (int k = 0; k < 6; ++k) acc[k] += h[g * 6 + k];
+    for (int k = 0; k < NSTAT; ++k) acc[k] += h[g * NSTAT + k];
   out->sims = acc[0]; out->sum_depth = acc[1]; out->sum_children = acc[2];
-  out->evals = acc[3]; out->terminals = acc[4]; out->expanded_edges = acc[5];
+  out->evals = acc[3]; out->terminals = acc[4]; out->expanded_edges = acc[5]; out->sum_touched = acc[6];
   return AZ_OK;
 }
 
 int az_reset_stats(az_engine *e, void *stream) {
   if (!e) return AZ_EINVAL;
   DeviceGuard guard(e->cfg.device);
-  AZ_HIP(hipMemsetAsync(e->v.stat, 0, (size_t)e->v.G * 6 * sizeof(unsigned long long), (hipStream_t)stream));
+  AZ_HIP(hipMemsetAsync(e->v.stat, 0, (size_t)e->v.G * NSTAT * sizeof(unsigned long long), (hipStream_t)stream));
   return AZ_OK;
 }
 

@@ -1,8 +1,8 @@
 // az_games.hip.h -- bitboard rules of the three games, for one wavefront per position.
 //
-// A state is SW u32 words kept in LDS.  Every function is called by all 64 lanes of the wave with
-// wave-uniform arguments unless it says "per lane".  apply() contains workgroup barriers, so it is
-// only usable from kernels launched with one wave per workgroup (blockDim.x == 64).
+// A state is SW u32 words kept in LDS, private to ONE wavefront.  Every function is called by all 64 lanes of the wave
+// with wave-uniform arguments unless it says "per lane".  Synchronisation is wave-level only (wave_sync: no s_barrier),
+// so several waves of one workgroup can each run a position of their own, at their own pace.
 //
 // Reference semantics (files under the reference tree):
 //   tictactoe  examples/tictactoe/game.py:20-77
@@ -18,6 +18,15 @@ namespace az {
 // terminal() results
 enum : int { T_NONE = 0, T_WIN_P1 = 1, T_WIN_P2 = 2, T_NO_WINNER = 3 };
 
+// Order this wave's own LDS / global accesses (lane 0 writes, all lanes read): a workgroup-scope fence for the memory
+// model and a wave barrier for the compiler -- NOT an s_barrier.  One wavefront executes in lock step and its LDS and
+// vector-memory instructions are issued in program order, so nothing else is needed between lanes of one wave; and
+// because no workgroup barrier is involved, the waves of a workgroup may take different numbers of steps.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ uint32_t bit_at(const uint32_t *w, int i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 
 // ------------------------------------------------------------------------------------------
@@ -31,9 +40,9 @@ struct TicTacToe {
   __device__ static bool same_player(const uint32_t *, int) { return false; }  // per lane
   __device__ static int apply(uint32_t *s, int a, int player, int lane) {
     uint32_t w = s[0] | (1u << (a + (player == 1 ? 0 : 9)));
-    __syncthreads();
+    wave_sync();
     if (lane == 0) s[0] = w;
-    __syncthreads();
+    wave_sync();
     return -player;
   }
   // after `mover` played `a`; nmoves = stones on the board
@@ -106,12 +115,12 @@ struct Dab {
   __device__ static int apply(uint32_t *s, int a, int player, int lane) {
     const uint32_t e = s[0], o = s[1];
     const uint32_t done = completed(e, o, a);
-    __syncthreads();
+    wave_sync();
     if (lane == 0) {
       s[0] = e | (1u << a);
       s[1] = o | (done << (player == 1 ? 0 : 9));
     }
-    __syncthreads();
+    wave_sync();
     return done ? player : -player;
   }
   __device__ static int terminal(const uint32_t *s, int, int, int, int) {
@@ -159,9 +168,9 @@ struct Gomoku {
   __device__ static int apply(uint32_t *s, int a, int player, int lane) {
     const int wi = (player == 1 ? 0 : WC) + (a >> 5);
     const uint32_t w = s[wi] | (1u << (a & 31));
-    __syncthreads();
+    wave_sync();
     if (lane == 0) s[wi] = w;
-    __syncthreads();
+    wave_sync();
     return -player;
   }
   // Only the mover can have made a five (the position before was not terminal), so the row-major

@@ -34,7 +34,8 @@ class AzDims(C.Structure):
 
 class AzStats(C.Structure):
     _fields_ = [("sims", C.c_uint64), ("sum_depth", C.c_uint64), ("sum_children", C.c_uint64),
-                ("evals", C.c_uint64), ("terminals", C.c_uint64), ("expanded_edges", C.c_uint64)]
+                ("evals", C.c_uint64), ("terminals", C.c_uint64), ("expanded_edges", C.c_uint64),
+                ("sum_touched", C.c_uint64)]
 
 
 EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check", "az_reset_games",

@@ -55,7 +55,14 @@ WORKLOADS = {
 }
 
 
+PRIOR_SHARPNESS = 1.0  # --prior-sharpness: the policy head's last Linear layer (weights and bias) is multiplied by this
+
+
 def make_model(workload: str):
+    """the workload's network, random init (seed 0).  A random-init network gives nearly flat priors, hence shallow trees
+    (mean selection depth 1.5 on gomoku 15x15); a TRAINED network's priors are peaked and its trees 4-8 levels deep.
+    --prior-sharpness s > 1 stands in for that: logits x s (folded into the policy head's last Linear layer, so the
+    evaluation costs exactly what it costs at s = 1).  Diagnostic only: the default line runs at s = 1."""
     import torch
     from alphazero_amd import nets
 
@@ -63,15 +70,23 @@ def make_model(workload: str):
     game = WORKLOADS[workload][0]
     if game == 2:
         kw = WORKLOADS[workload][4]
-        return (nets.QuickNet(**kw) if "layers" in kw else nets.GomokuNet(**kw)).eval()
-    return (nets.DotsAndBoxesNet() if game == 1 else nets.TicTacToeNet()).eval()
+        m = (nets.QuickNet(**kw) if "layers" in kw else nets.GomokuNet(**kw)).eval()
+    else:
+        m = (nets.DotsAndBoxesNet() if game == 1 else nets.TicTacToeNet()).eval()
+    if PRIOR_SHARPNESS != 1.0:
+        last = [x for x in m._policy_head if isinstance(x, torch.nn.Linear)][-1]
+        with torch.no_grad():
+            last.weight.mul_(PRIOR_SHARPNESS)
+            last.bias.mul_(PRIOR_SHARPNESS)
+    return m
 
 
 # ------------------------------------------------------------------------------ CPU baseline ----
 def _cpu_worker(args):
     """One single-threaded self-play worker on the CPU oracle (mirrors _self_player_worker,
     training/alphazero_trainer.py:164-221: torch.set_num_threads(1), own seed)."""
-    workload, seed, budget_s = args
+    global PRIOR_SHARPNESS
+    workload, seed, budget_s, PRIOR_SHARPNESS = args
     import numpy as np
     import torch
 
@@ -116,14 +131,20 @@ def cpu_baseline(workload: str, budget_s: float = 12.0) -> dict:
     workers = max(1, share - 2)  # the reference's "auto" rule: cores - 2 (config/train_config.py:35-38)
     ctx = mp.get_context("spawn")
     with ctx.Pool(workers) as pool:
-        res = pool.map(_cpu_worker, [(workload, 1000 + i, budget_s) for i in range(workers)])
+        res = pool.map(_cpu_worker, [(workload, 1000 + i, budget_s, PRIOR_SHARPNESS) for i in range(workers)])
     sims = sum(r[0] for r in res)
     wall = max(r[2] for r in res)
     game, n, nsims, _, _ = WORKLOADS[workload]
     return {"value": sims / wall, "unit": "sims/s", "cores": workers, "kind": "port",
             "sample": f"{workers} single-thread workers x {budget_s:.0f} s of {workload} self-play "
                       f"({nsims} sims/move, same net on torch-CPU, batch 1) on the CPU oracle",
-            "per_core": sims / wall / workers}
+            "per_core": sims / wall / workers,
+            # the reference's own Python, for orientation (measured in the survey container, 1 process,
+            # torch.set_num_threads(1), shimmed reference; it cannot run on the GPU box): labelled constants, not measurements of this run
+            "reference_python_1thread_sims_per_s": {"tictactoe": 1230, "dab": 370, "gomoku15": 59}.get(
+                "gomoku15" if workload.startswith("gomoku15") else workload),
+            "reference_python_where": "survey container, 8 host cores, one single-thread process (SURVEY.md section 6); README "
+                                      "wall-clock: tic-tac-toe 1000 games in 59 s, dots-and-boxes 3000 games in 1883 s (i9 + RTX 4070 laptop)"}
 
 
 # ------------------------------------------------------------------------------ GPU bench -------
@@ -169,8 +190,12 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph), graph_unit=args.graph_unit,
                          seed=SEED)
     run.game_ids.copy_(rank + world * torch.arange(slots, dtype=torch.int64))
-    if evaluator == "hash":  # tree kernels alone (no network)
-        run.evaluate = lambda: eng.eval_hash(run.nn_input, run.logits, run.values, 6.0)
+    if evaluator == "hash":  # tree kernels alone (no network): the synthetic evaluator reads the packed leaf batch, as the towers do
+        class _PackedOnly:  # (makes the runner pass nn_input = NULL: no dense planes are written)
+            kernel_events, generation = None, 0
+
+        run.fused = _PackedOnly()
+        run.evaluate = lambda: eng.eval_hash(None, run.logits, run.values, args.hash_scale)
     wave = eng.leaves_per_step > 1  # virtual loss / in-tree leaf batching: several leaves per tree per network batch
     ring = HostSampleRing(max(4 * slots, 65536), (d.nn_channels, d.height, d.width), d.n_action)
     esize = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}[tdtype]
@@ -392,14 +417,19 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     launches = sims * (1 if args.graph else steps)  # launches of each per-simulation kernel behind st_probe
     tree_ms, nn_ms = corr(tree_ms_raw), corr(nn_ms_raw)
     st = st_probe  # byte counts must come from the same launches the events bracket
-    # algorithmic bytes: child record = Q f64 + {P f32, N i32} + meta u32 = 20 B read by select,
-    # 12 B written at expansion (Q is not stored until the first visit);
-    # leaf batch = packed ring 32*SW B (+ the dense planes only when a PyTorch forward consumes them)
+    # algorithmic bytes.  A child record has a light part (prior f32 + action u8 = 5 B), read for every
+    # child a descent scans and written at expansion, and a heavy part ({visits, meta} 8 B + value f64 8 B) that exists -- and
+    # is read -- only for the children a descent has touched; a first touch writes 30 B (the swap of two light parts, the
+    # heavy part's initial values, the block's touched count).  Leaf batch = packed ring 32*SW B (+ the dense planes only
+    # when a PyTorch forward consumes them)
     planes = 0.0 if has_fused else nin * esize
-    sel_bytes = (20.0 * st["sum_children"] + 4.0 * st["sum_depth"] + st["evals"] * (32.0 * d.state_words + planes)
-                 + st["sims"] * (16.0 + 36.0 * d.state_words + 16.0)) / launches
-    exp_bytes = (st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 12.0 * st["expanded_edges"]
-                 + 32.0 * st["sum_depth"] + 36.0 * st["sims"]) / launches
+    fixed_sel = 4.0 * st["sum_depth"] + st["evals"] * (32.0 * d.state_words + planes) + st["sims"] * (16.0 + 36.0 * d.state_words + 16.0)
+    fixed_exp = st["evals"] * (4.0 * d.n_action + 4.0 + 4.0 * d.state_words) + 32.0 * st["sum_depth"] + 36.0 * st["sims"]
+    sel_bytes = (5.0 * st["sum_children"] + 16.0 * st["sum_touched"] + 30.0 * st["evals"] + fixed_sel) / launches
+    exp_bytes = (5.0 * st["expanded_edges"] + fixed_exp) / launches
+    # the same launches priced as round 2's layout would have moved them (20 B per scanned child, 12 B per new record):
+    # what the kernel's time is compared with when the question is "how much faster than the old layout's roofline"
+    r02_bytes = (20.0 * st["sum_children"] + fixed_sel + 12.0 * st["expanded_edges"] + fixed_exp) / launches
     # the tree work of a simulation step is ONE launch: backup of simulation i + descent of simulation i+1
     dom = ("k_expand_select", sel_bytes + exp_bytes, tree_ms)
     tower_kernel = "k_smallnet_f32" if game != 2 else ("k_tower_f32_t16" if dtype_name == "f32" else "k_tower")
@@ -423,7 +453,11 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     achieved = dom[1] / (dom[2] * 1e-3) / 1e9 if dom[2] > 0 else 0.0
     tree_roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": dom[1],
-                     "ms_per_launch": dom[2]}
+                     "ms_per_launch": dom[2],
+                     "round2_layout": {"bytes_per_launch": r02_bytes, "frac_at_this_time": (r02_bytes / (dom[2] * 1e-3) / 1e9 / 8000.0) if dom[2] > 0 else 0.0,
+                                       "note": "the same descents and expansions priced with round 2's 20-byte scanned / 12-byte written child "
+                                               "records: what this launch time would be as a fraction of 8 TB/s had the bytes not been cut"},
+                     "touched_share_of_scanned": st["sum_touched"] / max(st["sum_children"], 1)}
     evals_per_launch = st["evals"] / launches  # boards the network really evaluates per simulation step
     roofline = tree_roofline
     nn_eval = None
@@ -467,7 +501,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": f"{args.workload}: {sims} sims/move, {slots} concurrent games per GPU, "
                                f"evaluator={evaluator} ({dtype_name} network arithmetic), one step = one self-play move of every game",
-                   "slots_per_gpu": slots, "sims_per_move": sims, "parallelism": f"games sharded x{world}, no data-path collective"},
+                   "slots_per_gpu": slots, "sims_per_move": sims, "parallelism": f"games sharded x{world}, no data-path collective",
+                   **({"prior_sharpness": PRIOR_SHARPNESS} if PRIOR_SHARPNESS != 1.0 else {})},
         "plies_per_sec": slots * world * steps / elapsed,
         "games_per_sec_finished_in_window": total_games / elapsed,
         "games_per_sec": (slots * world * steps / elapsed / game_len["mean_plies"]) if game_len else None,
@@ -693,6 +728,11 @@ def main():
     ap.add_argument("--no-agreement", action="store_true", help="skip the f32-vs-bf16 decision-agreement measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the "
                     "barrier / all-reduce / weight-broadcast path on a one-GPU box")
+    ap.add_argument("--prior-sharpness", type=float, default=1.0, help="multiply the network's logits by this (folded into the policy head's "
+                    "last Linear layer): > 1 peaks the priors and deepens the trees the way a trained network does (a random-init network: "
+                    "mean depth 1.5).  Diagnostic for the tree kernels; reported in config.prior_sharpness")
+    ap.add_argument("--hash-scale", type=float, default=6.0, help="--evaluator hash: the synthetic evaluator's logits span +-scale/2 "
+                    "(6: mean depth ~2.3 at 200 sims; 40-100: the 4-8 levels deep trees of a trained network)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI, one rank per GPU (the measured "
                     "configuration).  gloo: the same N-rank code path with the collectives on host tensors, ranks may share a GPU "
                     "(local rank modulo the visible GPUs): a rehearsal of the N > 1 logic on a one-GPU box, not a measurement")
@@ -703,6 +743,8 @@ def main():
         args.graph = 1 if WORKLOADS[args.workload][3] <= 4096 and args.leaves <= 1 and args.evaluator != "hash" else 0
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    global PRIOR_SHARPNESS
+    PRIOR_SHARPNESS = float(args.prior_sharpness)
 
     # `python bench.py --gpus N` with no launcher around it: become the launcher (before torch is imported; this process
     # never touches a GPU) and let N children of this script be the ranks

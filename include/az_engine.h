@@ -73,10 +73,11 @@ typedef struct az_dims {
 typedef struct az_stats {
   uint64_t sims;          /* simulations run */
   uint64_t sum_depth;     /* sum of selection depths (edges followed) */
-  uint64_t sum_children;  /* child records scanned by select */
+  uint64_t sum_children;  /* child records scanned by select (light part: prior 4 B + action 1 B each) */
   uint64_t evals;         /* leaves that needed the network */
   uint64_t terminals;     /* leaves that were terminal positions */
   uint64_t expanded_edges;/* child records written by expand */
+  uint64_t sum_touched;   /* of sum_children, the records already touched, whose heavy part (visits, meta, value: 16 B) select also reads */
 } az_stats;
 
 /* Lifetime.  az_create sizes and allocates every array once; nothing else allocates. */

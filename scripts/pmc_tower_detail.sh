@@ -8,7 +8,7 @@
 set -e -o pipefail
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/tower_detail_$TAG
+OUT=$ROOT/gpurun_out/${DETAIL_PREFIX:-tower}_detail_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 0 --preroll 0 --no-cpu-baseline --no-agreement --game-probe 0 --secondary-steps 0 ${BENCH_ARGS:-}"
@@ -16,7 +16,7 @@ PASS_A="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WA
 PASS_B="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
 for P in A B; do
   V=PASS_$P
-  timeout -s KILL 300 rocprofv3 --pmc ${!V} --kernel-trace --kernel-include-regex "k_tower" \
+  timeout -s KILL 300 rocprofv3 --pmc ${!V} --kernel-trace --kernel-include-regex "${KERNEL_REGEX:-k_tower}" \
     --output-format csv -d $OUT/$P -o pmc -- python3 $ROOT/bench.py $ARGS > $OUT/run_$P.log 2>&1
   echo "pass $P done"
 done

@@ -560,6 +560,110 @@ def make_quick():
     print("quick", p.shape, v.shape)
 
 
+# --------------------------------------------------------------------------- full-board draw -------
+def five_free_colouring(n, seed=0):
+    """a colouring of the n x n board with ceil(n*n/2) first-player stones and no five in a row of either colour
+    (examples/gomoku/game.py:62-89 scans every 5-window in 4 directions), found by local search"""
+    rng = np.random.default_rng(seed)
+    N = n * n
+    windows = []
+    for r in range(n):
+        for c in range(n):
+            for dr, dc in ((0, 1), (1, 0), (1, 1), (1, -1)):
+                cells = [(r + k * dr, c + k * dc) for k in range(5)]
+                if all(0 <= rr < n and 0 <= cc < n for rr, cc in cells):
+                    windows.append([rr * n + cc for rr, cc in cells])
+    windows = np.array(windows)
+
+    def bad(col):
+        sums = col[windows].sum(1)
+        return int(((sums == 5) | (sums == 0)).sum())
+
+    col = np.zeros(N, np.int64)
+    col[rng.permutation(N)[:(N + 1) // 2]] = 1
+    cur = bad(col)
+    for _ in range(200000):
+        if cur == 0:
+            break
+        a, b = rng.choice(np.nonzero(col == 1)[0]), rng.choice(np.nonzero(col == 0)[0])
+        col[a], col[b] = 0, 1
+        nb = bad(col)
+        if nb <= cur:
+            cur = nb
+        else:
+            col[a], col[b] = 1, 0
+    assert cur == 0, "no five-free colouring found"
+    return col
+
+
+def make_draw():
+    """gomoku 9x9 played until the board is full with no five for either side: is_terminal True, _get_winner None,
+    terminal_evaluation 0 (examples/gomoku/game.py:47-52, games/base.py:104-114) -- the case random playouts never reach"""
+    GomokuGame.BOARD_SIZE = 9
+    col = five_free_colouring(9, seed=1)
+    p1, p2 = list(np.nonzero(col == 1)[0]), list(np.nonzero(col == 0)[0])
+    rng = np.random.default_rng(2)
+    rng.shuffle(p1), rng.shuffle(p2)
+    script = [int(x) for i in range(41) for x in ((p1[i], p2[i]) if i < 40 else (p1[i],))]
+    out = {f"g0_{k}": v for k, v in playout(GomokuGame, rng, script=script).items()}
+    assert len(out["g0_actions"]) == 81 and out["g0_terminal"][-1] and not out["g0_terminal"][:-1].any()
+    assert not out["g0_winner"].any(), "a five slipped in"
+    s = torch.from_numpy(out["g0_states"][-1].astype(np.float32)).view(9, 9)
+    assert GomokuGame.is_terminal(s) and GomokuGame._get_winner(s) is None
+    out["final_eval_p1"] = np.float32(GomokuGame.terminal_evaluation(s, 1))
+    out["final_eval_p2"] = np.float32(GomokuGame.terminal_evaluation(s, -1))
+    out["n_games"] = np.int32(1)
+    np.savez_compressed(os.path.join(OUT, "rules_gomoku9_draw.npz"), **out)
+    GomokuGame.BOARD_SIZE = 15
+    print("draw: 81 plies, evaluation", out["final_eval_p1"], out["final_eval_p2"])
+
+
+# --------------------------------------------------------------------------- shared ring KAT -------
+def make_ring():
+    """The reference's OWN SharedRingBufferExperiencePool (utils/share_ring_buffer.py:22-127) fed fixed samples through
+    put_tupule_experience, in two instalments, with a capacity smaller than the data (wrap-around, overwrite of the oldest
+    rows, read index pushed on): the samples and the ring's tensors / indices after each instalment, as data."""
+    from utils.share_ring_buffer import SharedRingBufferExperiencePool
+
+    rng = np.random.default_rng(123)
+    out = {}
+    tags = []
+
+    def case(tag, game_cls, cin, h, w, A, n1, n2, cap):
+        n = n1 + n2
+        st = rng.integers(-1, 2, size=(n, cin, h, w)).astype(np.float32)
+        if game_cls is DotsAndBoxesGame:
+            st[:] = 0
+            for b in range(8):
+                st[:, 3 * b, :, :3] = rng.integers(0, 2, size=(n, 4, 3))
+                st[:, 3 * b + 1, :3, :] = rng.integers(0, 2, size=(n, 3, 4))
+                st[:, 3 * b + 2, :3, :3] = rng.integers(-1, 2, size=(n, 3, 3))
+        st[:, -1] = rng.choice([-1.0, 1.0], size=(n, 1, 1))
+        pi = rng.random((n, A)).astype(np.float32)
+        z = rng.choice([-1.0, 0.0, 1.0], size=n).astype(np.float32)
+        pool = SharedRingBufferExperiencePool((1, cin, h, w), (1, A), game_cls, cap)
+        out[f"{tag}__states"], out[f"{tag}__pis"], out[f"{tag}__z"] = st.astype(np.int8), pi, z
+        out[f"{tag}__split"], out[f"{tag}__capacity"] = np.int32(n1), np.int32(cap)
+        for part, (lo, hi) in enumerate(((0, n1), (n1, n))):
+            for i in range(lo, hi):  # exactly what training/self_play.py:122-132 hands the pool
+                pool.put_tupule_experience((torch.from_numpy(st[i:i + 1]), torch.from_numpy(pi[i:i + 1]), torch.tensor([z[i]])))
+            out[f"{tag}__ring_states_{part}"] = pool._states.numpy().astype(np.int8).copy()
+            out[f"{tag}__ring_prior_{part}"] = pool._prior.numpy().copy()
+            out[f"{tag}__ring_values_{part}"] = pool._values.numpy().copy()
+            out[f"{tag}__idx_{part}"] = np.array([pool._write_idx.value, pool._read_idx.value, pool._size.value,
+                                                  pool._total_written.value], np.int64)
+        tags.append(tag)
+        print("ring", tag, n, "samples into", cap, "rows:", out[f"{tag}__idx_1"])
+
+    GomokuGame.BOARD_SIZE = 9
+    case("gomoku9", GomokuGame, 9, 9, 9, 81, 5, 6, 61)   # 88 rows into 61
+    case("tictactoe", TicTacToeGame, 9, 3, 3, 9, 7, 9, 100)  # 128 rows into 100, first instalment does not fill it
+    case("dab", DotsAndBoxesGame, 25, 4, 4, 24, 4, 5, 40)  # 72 rows into 40: more than one lap
+    GomokuGame.BOARD_SIZE = 15
+    out["tags"] = np.array(tags)
+    np.savez_compressed(os.path.join(OUT, "ring.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rules", "search", "selfplay", "augment", "loss", "quick"]
     if "quick" in which:
@@ -574,3 +678,7 @@ if __name__ == "__main__":
         make_selfplay()
     if "augment" in which:
         make_augment()
+    if "draw" in which:  # (added in round 3; not in the default list, so the older fixtures are not rewritten)
+        make_draw()
+    if "ring" in which:
+        make_ring()

@@ -407,6 +407,45 @@ def test_bulk_writer_fills_the_reference_ring_like_its_own_puts(name, game, n, A
     assert torch.equal(got._states, want._states) and torch.equal(got._prior, want._prior) and torch.equal(got._values, want._values)
 
 
+RING = None
+
+
+def _ring_cases():
+    global RING
+    if RING is None:
+        from .conftest import load_cases
+
+        RING = load_cases("ring.npz")
+    return RING
+
+
+@pytest.mark.parametrize("tag,game,n", [("tictactoe", 0, 3), ("dab", 1, 3), ("gomoku9", 2, 9)])
+def test_bulk_writer_against_the_references_own_ring(tag, game, n):
+    """tests/golden/ring.npz: the reference's SharedRingBufferExperiencePool itself (utils/share_ring_buffer.py:22-127), fed
+    fixed samples through put_tupule_experience in two instalments with a capacity smaller than the data.  SharedRingWriter
+    (GPU augmentation + one locked bulk write per instalment) must leave the same rows and the same write / read / size /
+    total indices after each instalment -- wrap-around, overwriting the oldest rows, more than one lap included."""
+    from alphazero_amd import Engine
+    from alphazero_amd.samples import SharedRingWriter
+
+    c = _ring_cases()[tag]
+    eng = Engine(game, 4, 4, board_size=n, device="cuda:0")
+    d = eng.dims
+    cap, split = int(c["capacity"]), int(c["split"])
+    ring = _RefLikeRing(cap, (d.nn_channels, d.height, d.width), d.n_action, game)  # (used as the bare fields here)
+    w = SharedRingWriter(ring, eng)
+    st = torch.from_numpy(c["states"].astype(np.float32))
+    pi, z = torch.from_numpy(c["pis"]), torch.from_numpy(c["z"])
+    for part, (lo, hi) in enumerate(((0, split), (split, st.shape[0]))):
+        assert w.put_batch(st[lo:hi], pi[lo:hi], z[lo:hi]) == 8 * (hi - lo)
+        idx = [ring._write_idx.value, ring._read_idx.value, ring._size.value, ring._total_written.value]
+        assert idx == c[f"idx_{part}"].tolist(), (part, idx)
+        assert np.array_equal(ring._states.numpy().astype(np.int8), c[f"ring_states_{part}"]), part
+        assert np.array_equal(ring._prior.numpy(), c[f"ring_prior_{part}"]), part
+        assert np.array_equal(ring._values.numpy(), c[f"ring_values_{part}"]), part
+    eng.close()
+
+
 @pytest.mark.parametrize("kind", ["gomokunet-128x4-fused-bf16", "quicknet-128x2x3-fused-f32", "quicknet-128x2x3-fused-bf16",
                                   "quicknet-128x2x3-pytorch-f32"])
 def test_config5_shape_self_play_train_loop(kind):

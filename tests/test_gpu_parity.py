@@ -59,7 +59,7 @@ def _run_search(eng, sims, evaluator, noise=None):
 @pytest.mark.parametrize("name,game,n,sims", CONFIGS)
 @pytest.mark.parametrize("nn_dtype", [torch.float32, torch.bfloat16])
 def test_search_matches_oracle_hash_net(oracle, name, game, n, sims, nn_dtype):
-    rng = np.random.default_rng(hash(name) % 1000)
+    rng = np.random.default_rng(1000 + 17 * game + n + sims)  # a fixed seed per case: a failure must reproduce (str hashes are salted per process)
     G = 24
     d = oracle.dims(game, n)
     eng = _engine(game, n, G, sims, nn_dtype=nn_dtype)

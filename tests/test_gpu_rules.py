@@ -16,6 +16,8 @@ from .conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 RULES = [("tictactoe", 0, 3), ("dab", 1, 3), ("gomoku15", 2, 15), ("gomoku9", 2, 9)]
+# + the full-board draw (81 plies, no five for either side: terminal, no winner, result 0; examples/gomoku/game.py:47-52)
+FIXTURES = RULES + [("gomoku9_draw", 2, 9)]
 
 
 def _two_sims(eng, nn, logits, values):
@@ -27,7 +29,7 @@ def _two_sims(eng, nn, logits, values):
         eng.expand_backup(logits, values, None)
 
 
-@pytest.mark.parametrize("name,game,n", RULES)
+@pytest.mark.parametrize("name,game,n", FIXTURES)
 def test_reference_rule_cases_through_the_hip_rules(name, game, n):
     from alphazero_amd import Engine
 
@@ -76,6 +78,8 @@ def test_reference_rule_cases_through_the_hip_rules(name, game, n):
                 assert result[g] == (0.0 if w == 0 else (1.0 if w == movers[g] else -1.0)), (name, g, k, "result")
                 alive[g] = False
     eng.check()
+    if name.endswith("_draw"):
+        assert not alive[0] and len(acts[0]) == A  # the board filled up and the game ended as a draw on the last ply
     # the final position of every finished game, from its trajectory: emitted sample 0 is the last position PLAYED FROM,
     # so replay the terminal board through the sample path instead: states of all plies via az_emit_samples
     fin = [g for g in range(G) if bool(z[f"g{g}_terminal"][-1])]

@@ -12,7 +12,9 @@ import pytest
 
 from .conftest import GOLDEN, game_of, load_cases
 
-RULES = [("tictactoe", 0, 3), ("dab", 1, 3), ("gomoku15", 2, 15), ("gomoku9", 2, 9)]
+# gomoku9_draw: a scripted 81-ply game that fills the board with no five for either side (the reference says terminal, no
+# winner, evaluation 0: examples/gomoku/game.py:47-52) -- the case random playouts never reach
+RULES = [("tictactoe", 0, 3), ("dab", 1, 3), ("gomoku15", 2, 15), ("gomoku9", 2, 9), ("gomoku9_draw", 2, 9)]
 
 
 @pytest.mark.parametrize("name,game,n", RULES)
@@ -30,6 +32,10 @@ def test_rules_kat(oracle, name, game, n):
             assert np.array_equal(oracle.legal_mask(game, n, s), z[f"g{g}_masks"][k])
             term, winner = oracle.status(game, n, s)
             assert term == bool(z[f"g{g}_terminal"][k]) and winner == z[f"g{g}_winner"][k], (g, k)
+    if name.endswith("_draw"):
+        assert term and winner == 0 and k == d["A"] - 1 and not z["g0_terminal"][:-1].any()
+        assert float(z["final_eval_p1"]) == 0.0 == float(z["final_eval_p2"])
+        return
     # error behaviour: occupied / out-of-range raise ValueError in the reference
     s = np.zeros(d["numel"], np.float32)
     s, _ = oracle.next_state(game, n, s, 0, 1)
