@@ -213,21 +213,31 @@ class SelfPlayRunner:
 
     def _search_waves(self, noise) -> None:
         """the search with virtual loss / in-tree leaf batching (engine created with leaves_per_step K > 1): every step
-        evaluates up to K leaves per tree in one network batch.  A tree whose descents collide on a pending leaf queues
-        fewer than K, so the number of steps is not known in advance: run the fewest that could suffice, then ask the
-        engine how many simulations the slowest tree still needs (one host sync per round) and go on."""
+        evaluates up to K leaves per tree in one network batch (rows whose flag is 0 -- unused leaves of a tree, trees that
+        are done -- cost no evaluation: the fused evaluators skip them).  A tree whose descents collide on a pending leaf
+        queues fewer than K, so the number of steps is not known in advance.  No host sync per step: the fewest steps that
+        could suffice plus a quarter are queued blind (a tree that is done idles through the rest), then the engine is asked
+        ONCE how many simulations the slowest tree still needs, and only a straggler costs further (synchronising) rounds."""
         e, K = self.e, self.e.leaves_per_step
         nn_in = None if self.fused is not None else self.nn_input
         e.begin_search()
-        left = self.num_sims
-        self.wave_steps = 0
-        while left > 0:
-            for _ in range((left + K - 1) // K):
+        self.wave_steps = self.wave_syncs = 0
+
+        def steps(n):
+            for _ in range(n):
                 e.select_wave(self.num_sims, nn_in)
                 self.evaluate()
                 e.expand_wave(self.logits, self.values, noise)
-                self.wave_steps += 1
+            self.wave_steps += n
+
+        need = (self.num_sims + K - 1) // K
+        steps(need + (need + 3) // 4)
+        while True:
             _, left = e.search_remaining(self.num_sims)
+            self.wave_syncs += 1
+            if left <= 0:
+                break
+            steps(max((left + K - 1) // K, 4))
 
     def move_round(self, inv_tao: torch.Tensor, forced: Optional[torch.Tensor] = None):
         """search + temperature sampling + step, for every active slot (training/self_play.py:36-83)"""
