@@ -97,8 +97,14 @@ class SelfPlayRunner:
             if engine.game == GAME_GOMOKU:
                 if engine.nn_dtype not in (torch.bfloat16, torch.float32):
                     raise EngineError("the fused evaluator exists in bf16 and f32: create the engine with one of these nn_dtypes")
-                # the engine's nn_dtype decides: f32 = the reference's own arithmetic (az_tower_f32.hip), bf16 = throughput mode
-                self.fused = FusedTowerEvaluator(model, "f32" if engine.nn_dtype == torch.float32 else "bf16")
+                # the engine's nn_dtype decides: f32 = the reference's own arithmetic (az_tower_f32.hip), bf16 = throughput mode;
+                # fused="f16x2" (f32 engine): az_tower_h2.hip, f32-level accuracy on the f16 MFMA pipe (secondary, by name only)
+                prec = "f32" if engine.nn_dtype == torch.float32 else "bf16"
+                if isinstance(fused, str):
+                    if fused not in ("f32", "bf16", "f16x2") or (fused == "bf16") != (prec == "bf16"):
+                        raise EngineError(f"fused={fused!r} does not fit an engine with nn_dtype {engine.nn_dtype}")
+                    prec = fused
+                self.fused = FusedTowerEvaluator(model, prec)
                 if self.fused.board != engine.dims.height:
                     raise EngineError("the fused evaluator's board does not match the engine's game")
             else:  # the reference's tic-tac-toe / dots-and-boxes networks: one f32 kernel per evaluation

@@ -60,6 +60,34 @@ def _pack3x3_f32(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
     return t.permute(0, 1, 2, 4, 3).contiguous().float()
 
 
+def _h2_scale(w: torch.Tensor) -> float:
+    """the power of two SW with max |w| * SW in (2^13, 2^14] (csrc/az_tower_h2.hip: both f16 halves of w * SW stay in f16's
+    normal range for weights down to 2^-14 of the largest), capped to [1, 2^20]"""
+    m = float(w.abs().max())
+    if not (m > 0.0):
+        return 1.0
+    import math
+
+    return float(2.0 ** max(0, min(20, 14 - math.ceil(math.log2(m)))))
+
+
+def _pack3x3_h2(w: torch.Tensor, cin_pad: int, scale: float) -> torch.Tensor:
+    """(co 64, ci, 3, 3) f32 -> [tap 9][k-step cin_pad/32][co tile 4][half 2][lane 64][8] f16 (csrc/az_tower_h2.hip): w * scale
+    split into two f16 halves, w1 = f16(w s), w2 = f16(w s - w1); lane = 16 kg + (co % 16) holds input channels
+    32 ks + 8 kg .. + 7 of output channel 16 ct + (lane % 16)"""
+    co, ci = w.shape[0], w.shape[1]
+    if ci < cin_pad:
+        w = torch.cat([w, w.new_zeros(co, cin_pad - ci, 3, 3)], 1)
+    ws = w.float() * scale
+    w1 = ws.half()
+    w2 = (ws - w1.float()).half()
+    parts = []
+    for h in (w1, w2):
+        t = h.permute(2, 3, 1, 0).reshape(9, cin_pad // 32, 4, 8, 4, 16)  # tap, ks, kg, j, ct, c
+        parts.append(t.permute(0, 1, 4, 2, 5, 3))  # tap, ks, ct, kg, c, j
+    return torch.stack(parts, 3).contiguous()  # tap, ks, ct, half, kg, c, j
+
+
 def _pack_linear_f32(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
     """(n, k) f32 Linear weight -> [n-tile][k-step k/8][half 2][n 32][4 k] f32, zero padded to (n_pad, k_pad)"""
     n, k = w.shape
@@ -157,6 +185,8 @@ class FusedTowerEvaluator:
             return "bf16"
         if dtype != torch.float32:
             return None
+        # (precision "f16x2" -- az_tower_h2.hip, f32-level accuracy on the f16 MFMA pipe, 64 channels -- is never picked by
+        # default: ask for it by name)
         ch, n_layers = model._shared_layers[0].out_channels, 2 * (len(model._shared_layers) - 3)
         return "f32" if ch == 64 or n_layers <= 40 else None  # (128 channels: the 16-cell-tile kernel only, bias table of 40 layers)
 
@@ -171,9 +201,11 @@ class FusedTowerEvaluator:
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
             raise EngineError("FusedTowerEvaluator needs the model on a GPU")
-        if precision not in ("bf16", "f32"):
-            raise EngineError("FusedTowerEvaluator: precision must be 'bf16' or 'f32'")
+        if precision not in ("bf16", "f32", "f16x2"):
+            raise EngineError("FusedTowerEvaluator: precision must be 'bf16', 'f32' or 'f16x2'")
         self.quick = self.quick_shape(model)
+        if precision == "f16x2" and (self.quick is not None or model._shared_layers[0].out_channels != 64):
+            raise EngineError("FusedTowerEvaluator: the f16x2 tower covers 64-channel GomokuModel-family networks")
         if self.quick is not None:
             self.board, self.ch, self.q_blocks, self.q_layers = self.quick
             self.n2 = self.board * self.board
@@ -190,7 +222,7 @@ class FusedTowerEvaluator:
         if precision == "f32" and self.precision_for(model, torch.float32) is None:
             raise EngineError("FusedTowerEvaluator: the f32 tower takes 128-channel trunks of at most 40 conv layers")
         self.precision = precision
-        self.in_dtype = torch.float32 if precision == "f32" else torch.bfloat16
+        self.in_dtype = torch.bfloat16 if precision == "bf16" else torch.float32  # (f16x2: f32 in, f32 feature rows, f32 heads)
         self._buf = {}
         self.kernel_events = None  # bench.py sets this to a list: (start, end) HIP events around the tower kernel alone
         self.refresh()
@@ -254,19 +286,32 @@ class FusedTowerEvaluator:
         m, dev = self.model, self.device
         sl = list(m._shared_layers)
         blocks = sl[3:]
-        f32 = self.precision == "f32"
+        f32 = self.precision != "bf16"  # (f16x2 shares the f32 heads and their packing)
+        h2 = self.precision == "f16x2"
         pack3 = _pack3x3_f32 if f32 else _pack3x3
         w, b = _fold(sl[0], sl[1])
-        _keep(self, "w0", pack3(w, 16), dev)
+        scales = [_h2_scale(w)] if h2 else None
+        _keep(self, "w0", _pack3x3_h2(w, 32, scales[0]) if h2 else pack3(w, 16), dev)
         biases, wl = [b], []
         for blk in blocks:
             for conv, bn in ((blk._conv1, blk._bn1), (blk._conv2, blk._bn2)):
                 w, b = _fold(conv, bn)
-                wl.append(pack3(w, self.ch))
+                if h2:
+                    scales.append(_h2_scale(w))
+                    wl.append(_pack3x3_h2(w, 64, scales[-1]))
+                else:
+                    wl.append(pack3(w, self.ch))
                 biases.append(b)
         self.n_layers = len(wl)
-        _keep(self, "wl", torch.stack(wl) if wl else torch.zeros(1, dtype=self.in_dtype), dev)
-        _keep(self, "bias", torch.stack(biases), dev)
+        _keep(self, "wl", torch.stack(wl) if wl else torch.zeros(1, dtype=torch.float16 if h2 else self.in_dtype), dev)
+        if h2:  # accumulators run at (true value) x SW_layer x SA (SA = 16: csrc/az_tower_h2.hip): the bias rows are pre-scaled
+            sw = torch.tensor(scales, dtype=torch.float32)
+            _keep(self, "sw", sw, dev)
+            _keep(self, "bias", torch.stack(biases).float().cpu() * sw.view(-1, 1) * 16.0, dev)
+            if getattr(self, "overflow", None) is None:
+                self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        else:
+            _keep(self, "bias", torch.stack(biases), dev)
         pw, pb = _fold(m._policy_head[0], m._policy_head[1])
         vw, vb = _fold(m._value_head[0], m._value_head[1])
         _keep(self, "headw", torch.cat([pw.view(1, self.ch), vw.view(2, self.ch)]), dev)
@@ -343,7 +388,13 @@ class FusedTowerEvaluator:
             if rc != 0:
                 raise EngineError(f"az_quick_heads_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
             return logits, value.view(B, 1)
-        if self.precision == "f32":
+        if self.precision == "f16x2":
+            if list_p is not None:
+                raise EngineError("the f16x2 tower takes the packed batch with flags (or all slots), not a compact list")
+            rc = self.lib.az_tower_forward_h2(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
+                                              flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.sw), P(self.headw), P(self.headb),
+                                              P(feat), self.feat_stride, P(self.overflow), st)
+        elif self.precision == "f32":
             if list_p is not None:
                 raise EngineError("the f32 tower takes the packed batch with flags (or all slots), not a compact list")
             rc = self.lib.az_tower_forward_f32(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
@@ -358,13 +409,18 @@ class FusedTowerEvaluator:
         if self.kernel_events is not None:
             ev1.record()
             self.kernel_events.append((ev0, ev1))
-        heads = self.lib.az_heads_forward_f32 if self.precision == "f32" else self.lib.az_heads_forward
+        heads = self.lib.az_heads_forward if self.precision == "bf16" else self.lib.az_heads_forward_f32
         rc = heads(self.board, B, P(feat), self.feat_stride, P(self.wp), P(self.bp), P(self.w1), P(self.b1),
                    P(self.w2), self.b2, P(logits), P(value), st)
         if rc != 0:
             raise EngineError(f"az_heads_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
         value = value.view(B, 1)
         return logits, value
+
+    def overflowed(self) -> bool:
+        """f16x2 only: True when an activation left f16's range (|x| > 4,094) in any evaluation so far -- the results are then
+        not to be trusted and the f32 tower must be used for this network.  Synchronises."""
+        return self.precision == "f16x2" and bool(int(self.overflow.item()))
 
     def forward_static(self, x: torch.Tensor | None, logits: torch.Tensor, values: torch.Tensor, packed=None, n_boards: int = 0):
         """The same evaluation through az_tower_heads_forward_static: nothing is allocated -- not here (the caller owns

@@ -148,7 +148,11 @@ def cpu_baseline(workload: str, budget_s: float = 12.0) -> dict:
 
 
 # ------------------------------------------------------------------------------ GPU bench -------
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f16x2": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
+# "f16x2" (az_tower_h2.hip): f32 operands split into two f16 halves, THREE f16 MFMAs per product block, f32 accumulation --
+# f32-level accuracy on the f16 pipe.  Its roofline counts the flops the MFMA pipe executes (3 x the convolution's) against the
+# f16 peak; the convolution's own flops per second are reported beside it as f32_equivalent_tflops.
+H2_MFMA_PER_PRODUCT = 3.0
 
 
 def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=True):
@@ -165,7 +169,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     game, n, sims, slots, _ = WORKLOADS[args.workload]
     sims = args.sims or sims
     slots = args.slots or slots
-    tdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype_name]
+    tdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f16x2": torch.float32}[dtype_name]
+    h2 = dtype_name == "f16x2"
     model = make_model(args.workload).to(dev)
     if tdtype != torch.float32:
         model = model.to(tdtype)
@@ -187,8 +192,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
         ok = FusedTowerEvaluator.precision_for(model, tdtype) is not None  # (QuickModel family: f32 tower only)
         ok = ok or (game != 2 and tdtype == torch.float32 and SmallNetEvaluator.supports(model))  # az_smallnet.hip (f32 only)
         evaluator = "fused" if ok else "model"
-    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph), graph_unit=args.graph_unit,
-                         seed=SEED)
+    run = SelfPlayRunner(eng, model, sims, channels_last=True, fused=("f16x2" if h2 else evaluator == "fused"), use_graph=bool(args.graph),
+                         graph_unit=args.graph_unit, seed=SEED)
     run.game_ids.copy_(rank + world * torch.arange(slots, dtype=torch.int64))
     if evaluator == "hash":  # tree kernels alone (no network): the synthetic evaluator reads the packed leaf batch, as the towers do
         class _PackedOnly:  # (makes the runner pass nn_input = NULL: no dense planes are written)
@@ -372,8 +377,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     game_len = None
     if rank == 0 and with_probe and args.game_probe > 0 and evaluator != "hash":
         pe = Engine(game, args.game_probe, sims, board_size=n, nn_dtype=tdtype, device=dev, leaves_per_step=max(args.leaves, 1))
-        pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=(evaluator == "fused"), use_graph=bool(args.graph), graph_unit=args.graph_unit,
-                            seed=SEED)
+        pr = SelfPlayRunner(pe, model, sims, channels_last=True, fused=("f16x2" if h2 else evaluator == "fused"), use_graph=bool(args.graph),
+                            graph_unit=args.graph_unit, seed=SEED)
         pr.game_ids += 1 << 40  # (games of their own, outside every rank's id range)
         pit = torch.full((args.game_probe,), 1.0 / reference_tao(0), device=dev)
         lengths, moves, tp0 = [], 0, time.perf_counter()
@@ -432,7 +437,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     r02_bytes = (20.0 * st["sum_children"] + fixed_sel + 12.0 * st["expanded_edges"] + fixed_exp) / launches
     # the tree work of a simulation step is ONE launch: backup of simulation i + descent of simulation i+1
     dom = ("k_expand_select", sel_bytes + exp_bytes, tree_ms)
-    tower_kernel = "k_smallnet_f32" if game != 2 else ("k_tower_f32_t16" if dtype_name == "f32" else "k_tower")
+    tower_kernel = "k_smallnet_f32" if game != 2 else ("k_tower_f32_t16" if dtype_name == "f32" else "k_tower_h2" if h2 else "k_tower")
 
     # HBM traffic from PMC counters cannot be collected inside this run (separate rocprofv3 --pmc passes,
     # scripts/pmc_traffic.sh); the last committed measurement of this same workload is reported, if present
@@ -477,6 +482,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
                                         if dtype_name == "f32" else "az_tower.hip: k_tower<QuickModel> (fused bf16 MFMA conv tower, 3x3 head convs) + k_quick_heads")
                                        if "layers" in WORKLOADS[args.workload][4] else
                                        "az_tower_f32.hip: k_tower_f32_t16 (f32 MFMA conv tower, 16-cell tiles) + k_heads_f32" if dtype_name == "f32" else
+                                       "az_tower_h2.hip: k_tower_h2 (f32 operands as two f16 halves, three f16 MFMAs per product, f32 accumulation) + k_heads_f32" if h2 else
                                        "az_tower.hip: k_tower (fused bf16 MFMA conv tower) + k_heads (MFMA head linears)")
                                       if evaluator == "fused" else "PyTorch/MIOpen module forward")}
         if evaluator == "fused" and tower_ms_raw is not None:
@@ -484,11 +490,18 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
             # multiply-adds x 2 for the boards this launch evaluates (terminal leaves are skipped, padding is not counted)
             tw_ms = corr(tower_ms_raw)
             tw_fl = (conv_flops if game == 2 else flops_per_eval) * evals_per_launch  # k_smallnet_f32 holds the head layers too
+            f32_equiv = tw_fl / (tw_ms * 1e-3) / 1e12
+            if h2:
+                tw_fl *= H2_MFMA_PER_PRODUCT  # what the f16 pipe executes
             ttraffic, tnote = pmc_traffic(tower_kernel)
             net_roofline = {"bound": "mfma", "kernel": tower_kernel, "achieved": tw_fl / (tw_ms * 1e-3) / 1e12, "peak": peak,
                         "unit": "TFLOP/s", "frac": tw_fl / (tw_ms * 1e-3) / 1e12 / peak, "traffic": ttraffic,
                         "traffic_note": tnote, "flops_per_launch": tw_fl, "boards_per_launch": evals_per_launch,
                         "ms_per_launch": tw_ms, "share_of_step": tw_ms / max(nn_ms + tree_ms, 1e-9)}
+            if h2:
+                net_roofline["f32_equivalent_tflops"] = f32_equiv
+                net_roofline["note"] = ("achieved / peak count the f16 MFMA flops executed (3 per multiply-add of the convolution: w1 x1 + w1 x2 + "
+                                        "w2 x1); f32_equivalent_tflops = the convolution's own flops per second, comparable with the f32 tower's 'achieved'")
             # the dominant kernel of the step: the network kernel for the gomoku towers; for the two small nets the tree
             # kernel runs longer than the whole network and stays the headline roofline
             if game == 2 or tw_ms >= tree_ms:
@@ -527,8 +540,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     return out
 
 
-def decision_agreement(args, dev, n_pos=1024, plies=12):
-    """How often does the bf16 throughput mode decide like the f32 network?  The same n_pos mid-game positions (reached by
+def decision_agreement(args, dev, n_pos=1024, plies=12, other="bf16"):
+    """How often does another evaluator (the bf16 throughput mode; the f16x2 tower) decide like the f32 network?  The same n_pos mid-game positions (reached by
     `plies` moves of cheap self-play), the same Dirichlet rows, the full search with each precision: fraction of roots
     whose most-visited move is the same, whose move sampled with the same exponential row is the same, and whose whole
     visit vector is identical."""
@@ -545,10 +558,10 @@ def decision_agreement(args, dev, n_pos=1024, plies=12):
     torch.cuda.manual_seed(99)
     res, pos_moves = {}, None
     noise = expo = None
-    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    for name, dt in (("f32", torch.float32), (other, torch.bfloat16 if other == "bf16" else torch.float32)):
         model = make_model(args.workload).to(dev).to(dt)
         eng = Engine(game, n_pos, sims, board_size=n, nn_dtype=dt, device=dev)
-        run = SelfPlayRunner(eng, model, sims, fused=True)
+        run = SelfPlayRunner(eng, model, sims, fused=(True if name != "f16x2" else "f16x2"))
         A = eng.dims.n_action
         it = torch.ones(n_pos, device=dev)
         if pos_moves is None:  # the opening moves, played once (hash evaluator, 8 sims) and replayed for the other precision
@@ -584,7 +597,7 @@ def decision_agreement(args, dev, n_pos=1024, plies=12):
         res[name] = (visits.clone(), (pi / expo).argmax(1), active.bool().clone())
         del run
         eng.close()
-    (v32, s32, a32), (v16, s16, a16) = res["f32"], res["bf16"]
+    (v32, s32, a32), (v16, s16, a16) = res["f32"], res[other]
     live = a32 & a16
     nl = max(int(live.sum()), 1)
     return {"positions": nl, "sims_per_move": sims,
@@ -593,7 +606,7 @@ def decision_agreement(args, dev, n_pos=1024, plies=12):
             "identical_visit_vectors": float((v32 == v16).all(1)[live].sum()) / nl,
             "mean_abs_pi_difference": float(((v32.float() - v16.float()).abs().sum(1) / max(sims - 1, 1))[live].mean()) / 2,
             "how": f"{nl} positions {plies} plies into a game, same Dirichlet and exponential rows, full search with the f32 tower "
-                   "(az_tower_f32.hip) and with the bf16 tower (az_tower.hip); mean_abs_pi_difference = total variation "
+                   f"(az_tower_f32.hip) and with the {other} tower ({'az_tower.hip' if other == 'bf16' else 'az_tower_h2.hip'}); mean_abs_pi_difference = total variation "
                    "distance between the two root visit distributions"}
 
 
@@ -802,6 +815,10 @@ def main():
     second = None
     if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1:
         second = measure(args, "bf16", sec_steps, 1, dev, rank, world, dst)
+    third = None
+    if primary == "f32" and sec_steps > 0 and args.workload in ("gomoku15", "gomoku9", "gomoku15_deep64") and args.evaluator in ("auto", "fused") \
+            and args.leaves <= 1:
+        third = measure(args, "f16x2", sec_steps, 1, dev, rank, world, dst, with_probe=False)
     ranks_seen = dst.gather_objects({"rank": rank, "device": dev_index, "pid": os.getpid()}) if dst is not None else None
     if rank == 0:
         out["cpu_baseline"] = cpu
@@ -816,7 +833,17 @@ def main():
             if not args.no_agreement:
                 second["decision_agreement"] = decision_agreement(args, dev)
             out["throughput_mode"] = second
-        elif world > 1:
+        if third is not None:
+            third["note"] = ("EXPLORATORY, secondary: the same workload with az_tower_h2.hip -- every f32 operand of the convolutions split into two f16 "
+                             "halves, three f16 MFMAs per product, f32 accumulation: f32-LEVEL ACCURACY (tests/test_gpu_tower_h2.py holds it to the f32 "
+                             "tower's bars against an f64 evaluation), but not the reference's arithmetic and not bit-equal to the f32 tower: never the headline")
+            third["speedup_vs_f32_line"] = third["value"] / out["value"]
+            if cpu:
+                third["speedup_vs_cpu_baseline_f32_network"] = third["value"] / cpu["value"]
+            if not args.no_agreement:
+                third["decision_agreement"] = decision_agreement(args, dev, other="f16x2")
+            out["f32_accurate_mode"] = third
+        if second is None and world > 1:
             out["throughput_mode"] = None
             out["throughput_mode_why"] = ("the bf16 line, the decision-agreement measurement and the game-length probe of the other "
                                           "precision run at one GPU only (--secondary-steps K forces the bf16 line at N > 1)")

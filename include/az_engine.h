@@ -232,6 +232,19 @@ int az_augment_samples(az_engine *e, int32_t n, const float *states_dev, const f
 int az_read_stats(az_engine *e, az_stats *out, void *stream);
 int az_reset_stats(az_engine *e, void *stream);
 
+/* EXPLORATORY, SECONDARY (csrc/az_tower_h2.hip): the 64-channel GomokuModel-family tower (the network az_tower_forward_f32
+ * evaluates; model contract nn_models/base.py:17-19) at f32-LEVEL ACCURACY on the f16 MFMA pipe -- every f32 operand split
+ * into two f16 halves (22 significant bits), w x = w1 x1 + w1 x2 + w2 x1 on v_mfma_f32_16x16x32_f16 with f32 accumulation.
+ * NOT the reference's arithmetic and not bit-equal to the f32 tower; same inputs / feature rows as az_tower_forward_f32
+ * (finish with az_heads_forward_f32).  w0_dev / wl_dev: [tap 9][k-step][co tile 4][half 2][lane 64][8] f16 of w * sw[layer];
+ * bias_scaled_dev (1 + n_conv_layers, 64) f32 = bias * sw[layer] * 16; sw_dev (1 + n_conv_layers) f32 powers of two
+ * (alphazero_amd.fused packs them).  overflow_dev (1) i32, may be NULL: set to 1 when an activation exceeds f16's range
+ * (|x| > 4,094) -- results are then invalid and the caller must use the f32 tower. */
+int az_tower_forward_h2(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const float *x_f32_dev,
+                        const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev, const void *w0_dev,
+                        const void *wl_dev, const float *bias_scaled_dev, const float *sw_dev, const float *headw_dev,
+                        const float *headb_dev, float *feat_f32_dev, int32_t feat_stride, int32_t *overflow_dev, void *stream);
+
 /* No counterpart in the reference: a deterministic synthetic evaluator ("hash network") with exact
  * f32 outputs, so tree parity can be tested bit for bit without a neural network and the tree
  * kernels can be benchmarked alone.  Reads the batch written by az_select_gather; nn_input_dev == NULL: reads the packed

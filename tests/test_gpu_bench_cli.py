@@ -39,6 +39,9 @@ def test_bench_line_gomoku_f32_primary_with_bf16_beside_it_under_rccl():
     assert t["dtype"] == "bf16" and t["roofline"]["kernel"] == "k_tower" and t["roofline"]["peak"] == 2500.0
     a = t["decision_agreement"]
     assert 0.5 <= a["same_most_visited_move"] <= 1.0 and a["positions"] > 0
+    h = d["f32_accurate_mode"]  # the split-operand f16 tower: a third, secondary line
+    assert h["dtype"] == "f16x2" and h["roofline"]["kernel"] == "k_tower_h2" and h["roofline"]["peak"] == 2500.0
+    assert h["roofline"]["f32_equivalent_tflops"] > 0 and h["decision_agreement"]["same_most_visited_move"] >= 0.9
 
 
 def test_bench_line_small_game_fused_and_through_pytorch():

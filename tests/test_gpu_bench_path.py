@@ -98,10 +98,11 @@ def _tower_callback(ev, shape, dtype):
     return O.EVAL_FN(_cb), calls
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f32", "f32-quick", "bf16-quick"])
+@pytest.mark.parametrize("precision", ["bf16", "f32", "f32-quick", "bf16-quick", "f16x2"])
 def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     """engine + tower on the packed/flags path == oracle + the same tower as its evaluator ("f32-quick": the reference's
-    QuickModel family, 128 channels, on the f32 tower's QuickModel instantiation -- config 5's network)"""
+    QuickModel family, 128 channels, on the f32 tower's QuickModel instantiation -- config 5's network; "f16x2": the
+    split-operand tower of az_tower_h2.hip on an f32 engine)"""
     from alphazero_amd import Engine
     from alphazero_amd.arena import SelfPlayRunner
     from alphazero_amd.nets import GomokuNet, QuickNet
@@ -116,8 +117,8 @@ def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     pos = _positions(oracle, G, rng, n)
     for g, (h, p) in enumerate(pos):
         eng.set_position(g, h, p)
-    run = SelfPlayRunner(eng, net, sims, fused=True)
-    assert run.fused is not None
+    run = SelfPlayRunner(eng, net, sims, fused="f16x2" if precision == "f16x2" else True)
+    assert run.fused is not None and run.fused.precision == precision.split("-")[0]
     noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
     _fix_noise(run, noise_np)
     run.search()
