@@ -63,7 +63,7 @@ __device__ __forceinline__ void split(float v, _Float16 &a, _Float16 &b) {
 // acc[pt][ct] += W x over the 9 taps; `w` points at this layer's packed weights, `wnext` at the next layer's (its first
 // fragments are requested under this layer's last k-step), `a` holds the fragments of the first k-step on entry and of
 // the next layer's first k-step on exit.
-template <int N, int KS>
+template <int N, int KS, bool X2 = true>
 __device__ __forceinline__ void conv_layer(const char *act, const char *__restrict__ w, const char *__restrict__ wnext, const int cg,
                                            const int lane, const int ntiles, const int (&cellb)[Geo<N>::TPW], const unsigned long long (&vm)[2],
                                            f4 (&acc)[Geo<N>::TPW][2], h8 (&a)[2][2]) {
@@ -95,7 +95,7 @@ __device__ __forceinline__ void conv_layer(const char *act, const char *__restri
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) {
             acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ct][1], b0, acc[pt][ct], 0, 0, 0);
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ct][0], b1, acc[pt][ct], 0, 0, 0);
+            if (X2) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ct][0], b1, acc[pt][ct], 0, 0, 0);  // (x2 == 0: adds nothing)
             acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ct][0], b0, acc[pt][ct], 0, 0, 0);
           }
         }
@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void k_tower_h2(const float *__restrict__ x
 
     // ---- stem
     init(0);
-    conv_layer<N, 1>(act, w0, L > 0 ? wl : w0, cg, lane, ntiles, cellb, vm, acc, a);
+    // (the packed input is +-16 / 0: exact in its first f16 half, so the stem needs two products, not three)
+    if (x == nullptr) conv_layer<N, 1, false>(act, w0, L > 0 ? wl : w0, cg, lane, ntiles, cellb, vm, acc, a);
+    else conv_layer<N, 1, true>(act, w0, L > 0 ? wl : w0, cg, lane, ntiles, cellb, vm, acc, a);
     __syncthreads();  // every wave has read the layer's input: the outputs may overwrite it
     epilogue(0, false);
     __syncthreads();
