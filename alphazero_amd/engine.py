@@ -45,7 +45,7 @@ EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check"
            "az_tower_heads_forward_static", "az_static_max_boards", "az_tower_forward_f32", "az_heads_forward_f32",
            "az_select_wave", "az_expand_wave", "az_search_remaining", "az_set_virtual_loss", "az_smallnet_forward_f32",
            "az_quick_tower_forward_f32", "az_quick_heads_forward_f32", "az_quick_stash_bytes", "az_quick_tower_forward", "az_quick_heads_forward",
-           "az_smallnet_head_floats", "az_draw_rng", "az_philox4x32_10", "az_tower_forward_h2"]
+           "az_smallnet_head_floats", "az_draw_rng", "az_philox4x32_10", "az_tower_forward_h2", "az_tower_forward_h1"]
 
 _lib = None
 
@@ -111,6 +111,7 @@ def load_library() -> C.CDLL:
     lib.az_draw_rng.argtypes = [vp, C.c_uint64, vp, C.c_float, vp, vp, vp]
     lib.az_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.az_tower_forward_h2.argtypes = [C.c_int32] * 4 + [vp] * 11 + [C.c_int32, vp, vp]
+    lib.az_tower_forward_h1.argtypes = [C.c_int32] * 5 + [vp] * 11 + [C.c_int32, C.c_int32, vp, vp]
     lib.az_tower_last_error.argtypes = []
     lib.az_tower_last_error.restype = C.c_char_p
     for name in EXPORTS:

@@ -88,6 +88,31 @@ def _pack3x3_h2(w: torch.Tensor, cin_pad: int, scale: float) -> torch.Tensor:
     return torch.stack(parts, 3).contiguous()  # tap, ks, ct, half, kg, c, j
 
 
+def _pack3x3_h1(w: torch.Tensor, cin_pad: int, scale: float, dtype: torch.dtype) -> torch.Tensor:
+    """(co 64, ci, 3, 3) f32 -> [tap 9][k-step cin_pad/32][co tile 4][lane 64][8] f16 | bf16 of w * scale (csrc/az_tower_h1.hip);
+    lane = 16 kg + m holds input channels 32 ks + 8 kg .. + 7 of the output channel in row m of co tile ct (order below)"""
+    co, ci = w.shape[0], w.shape[1]
+    if ci < cin_pad:
+        w = torch.cat([w, w.new_zeros(co, cin_pad - ci, 3, 3)], 1)
+    # row m of co tile ct is output channel 32 (ct // 2) + 8 (m // 4) + 4 (ct % 2) + m % 4: a lane's results of a wave's two
+    # tiles (rows 4 kg .. 4 kg + 3 of each) are then eight consecutive channels, one 16-byte store
+    perm = [32 * (t // 2) + 8 * (m // 4) + 4 * (t % 2) + m % 4 for t in range(4) for m in range(16)]
+    w = w[perm]
+    t = (w.float() * scale).to(dtype).permute(2, 3, 1, 0).reshape(9, cin_pad // 32, 4, 8, 4, 16)  # tap, ks, kg, j, ct, c
+    return t.permute(0, 1, 4, 2, 5, 3).contiguous()  # tap, ks, ct, kg, c, j
+
+
+def _pack_stem_h1(w: torch.Tensor, scale: float, dtype: torch.dtype) -> torch.Tensor:
+    """(co 64, 9, 3, 3) f32 -> [kernel row 3][co tile 4][lane 64][8] (csrc/az_tower_h1.hip): one k-step per kernel row, k = 9 tx +
+    plane (27 of 32 used); output rows ordered as in _pack3x3_h1"""
+    perm = [32 * (t // 2) + 8 * (m // 4) + 4 * (t % 2) + m % 4 for t in range(4) for m in range(16)]
+    ws = (w.float() * scale)[perm]  # (64, 9, 3, 3)
+    k = w.new_zeros(64, 3, 32)  # co, dy, k
+    k[:, :, :27] = ws.permute(0, 2, 3, 1).reshape(64, 3, 27)  # k = 9 tx + plane
+    t = k.to(dtype).reshape(4, 16, 3, 4, 8)  # ct, m, dy, kg, i
+    return t.permute(2, 0, 3, 1, 4).contiguous()  # dy, ct, kg, m, i
+
+
 def _pack_linear_f32(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
     """(n, k) f32 Linear weight -> [n-tile][k-step k/8][half 2][n 32][4 k] f32, zero padded to (n_pad, k_pad)"""
     n, k = w.shape
@@ -201,11 +226,14 @@ class FusedTowerEvaluator:
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
             raise EngineError("FusedTowerEvaluator needs the model on a GPU")
-        if precision not in ("bf16", "f32", "f16x2"):
-            raise EngineError("FusedTowerEvaluator: precision must be 'bf16', 'f32' or 'f16x2'")
+        if precision not in ("bf16", "f32", "f16x2", "f16", "bf16r"):
+            raise EngineError("FusedTowerEvaluator: precision must be 'bf16', 'f32', 'f16x2', 'f16' or 'bf16r'")
         self.quick = self.quick_shape(model)
         if precision == "f16x2" and (self.quick is not None or model._shared_layers[0].out_channels != 64):
             raise EngineError("FusedTowerEvaluator: the f16x2 tower covers 64-channel GomokuModel-family networks")
+        if precision in ("f16", "bf16r") and (self.quick is not None or model._shared_layers[0].out_channels != 64
+                                              or model._policy_head[4].in_features != 225):
+            raise EngineError("FusedTowerEvaluator: the row-tile tower (f16 / bf16r) covers 64-channel GomokuModel-family networks on 15x15")
         if self.quick is not None:
             self.board, self.ch, self.q_blocks, self.q_layers = self.quick
             self.n2 = self.board * self.board
@@ -222,7 +250,8 @@ class FusedTowerEvaluator:
         if precision == "f32" and self.precision_for(model, torch.float32) is None:
             raise EngineError("FusedTowerEvaluator: the f32 tower takes 128-channel trunks of at most 40 conv layers")
         self.precision = precision
-        self.in_dtype = torch.bfloat16 if precision == "bf16" else torch.float32  # (f16x2: f32 in, f32 feature rows, f32 heads)
+        self.in_dtype = torch.bfloat16 if precision == "bf16" else torch.float32  # (f16x2, f16, bf16r: f32 dense input)
+        self.feat_dtype = torch.bfloat16 if precision in ("bf16", "bf16r") else torch.float32  # bf16 rows + bf16 heads, or f32 rows + f32 heads
         self._buf = {}
         self.kernel_events = None  # bench.py sets this to a list: (start, end) HIP events around the tower kernel alone
         self.refresh()
@@ -286,28 +315,34 @@ class FusedTowerEvaluator:
         m, dev = self.model, self.device
         sl = list(m._shared_layers)
         blocks = sl[3:]
-        f32 = self.precision != "bf16"  # (f16x2 shares the f32 heads and their packing)
-        h2 = self.precision == "f16x2"
-        pack3 = _pack3x3_f32 if f32 else _pack3x3
+        f32 = self.precision not in ("bf16", "bf16r")  # (f16x2 and f16 share the f32 tower's heads and their packing)
+        h1 = self.precision in ("f16", "bf16r")  # the row-tile tower: one 16-bit product, f16 scaled like f16x2 or plain bf16
+        h2 = self.precision == "f16x2" or h1
+        h1_dtype = torch.bfloat16 if self.precision == "bf16r" else torch.float16
+        # (the row-tile tower's f16 scales stop at 2^15: the next layer's scale rides on an f16 operand of the residual MFMA)
+        scale_of = (lambda w: 1.0) if self.precision == "bf16r" else (lambda w: min(_h2_scale(w), 32768.0)) if h1 else _h2_scale
+        pack_h = (lambda w, cin, sc: _pack3x3_h1(w, cin, sc, h1_dtype)) if h1 else _pack3x3_h2
+        pack3 = _pack3x3_f32 if self.precision == "f32" else _pack3x3
         w, b = _fold(sl[0], sl[1])
-        scales = [_h2_scale(w)] if h2 else None
-        _keep(self, "w0", _pack3x3_h2(w, 32, scales[0]) if h2 else pack3(w, 16), dev)
+        scales = [scale_of(w)] if h2 else None
+        _keep(self, "w0", _pack_stem_h1(w, scales[0], h1_dtype) if h1 else pack_h(w, 32, scales[0]) if h2 else pack3(w, 16), dev)
         biases, wl = [b], []
         for blk in blocks:
             for conv, bn in ((blk._conv1, blk._bn1), (blk._conv2, blk._bn2)):
                 w, b = _fold(conv, bn)
                 if h2:
-                    scales.append(_h2_scale(w))
-                    wl.append(_pack3x3_h2(w, 64, scales[-1]))
+                    scales.append(scale_of(w))
+                    wl.append(pack_h(w, 64, scales[-1]))
                 else:
                     wl.append(pack3(w, self.ch))
                 biases.append(b)
         self.n_layers = len(wl)
-        _keep(self, "wl", torch.stack(wl) if wl else torch.zeros(1, dtype=torch.float16 if h2 else self.in_dtype), dev)
-        if h2:  # accumulators run at (true value) x SW_layer x SA (SA = 16: csrc/az_tower_h2.hip): the bias rows are pre-scaled
+        wl_dtype = h1_dtype if h1 else torch.float16 if h2 else self.in_dtype
+        _keep(self, "wl", torch.stack(wl) if wl else torch.zeros(1, dtype=wl_dtype), dev)
+        if h2:  # accumulators run at (true value) x SW_layer x SA (SA = 16, bf16r: 1; csrc/az_tower_h2.hip): the bias rows are pre-scaled
             sw = torch.tensor(scales, dtype=torch.float32)
             _keep(self, "sw", sw, dev)
-            _keep(self, "bias", torch.stack(biases).float().cpu() * sw.view(-1, 1) * 16.0, dev)
+            _keep(self, "bias", torch.stack(biases).float().cpu() * sw.view(-1, 1) * (1.0 if self.precision == "bf16r" else 16.0), dev)
             if getattr(self, "overflow", None) is None:
                 self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         else:
@@ -351,7 +386,7 @@ class FusedTowerEvaluator:
             count_p = C.c_void_p(packed[3]) if len(packed) > 3 and packed[3] else None
             flags_p = C.c_void_p(packed[4]) if len(packed) > 4 and packed[4] else None
         if B not in self._buf:  # zeroed once: the kernels never write the pad columns, and the heads multiply them by zero weights
-            self._buf[B] = (torch.zeros(B, self.feat_stride, dtype=self.in_dtype, device=self.device),
+            self._buf[B] = (torch.zeros(B, self.feat_stride, dtype=getattr(self, "feat_dtype", self.in_dtype), device=self.device),
                             torch.empty(B, self.n2, device=self.device), torch.empty(B, device=self.device))
         feat, logits_own, value = self._buf[B]
         logits = logits_out if logits_out is not None else logits_own
@@ -388,7 +423,14 @@ class FusedTowerEvaluator:
             if rc != 0:
                 raise EngineError(f"az_quick_heads_forward failed ({rc}): {self.lib.az_tower_last_error().decode()}")
             return logits, value.view(B, 1)
-        if self.precision == "f16x2":
+        if self.precision in ("f16", "bf16r"):
+            if list_p is not None:
+                raise EngineError("the row-tile tower takes the packed batch with flags (or all slots), not a compact list")
+            rc = self.lib.az_tower_forward_h1(self.board, self.ch, B, self.n_layers, 1 if self.precision == "bf16r" else 0,
+                                              P(x) if x is not None else None, ring_p, leaf_p, flags_p, P(self.w0), P(self.wl),
+                                              P(self.bias), P(self.sw), P(self.headw), P(self.headb), P(feat),
+                                              1 if self.precision == "bf16r" else 0, self.feat_stride, P(self.overflow), st)
+        elif self.precision == "f16x2":
             if list_p is not None:
                 raise EngineError("the f16x2 tower takes the packed batch with flags (or all slots), not a compact list")
             rc = self.lib.az_tower_forward_h2(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
@@ -409,7 +451,7 @@ class FusedTowerEvaluator:
         if self.kernel_events is not None:
             ev1.record()
             self.kernel_events.append((ev0, ev1))
-        heads = self.lib.az_heads_forward if self.precision == "bf16" else self.lib.az_heads_forward_f32
+        heads = self.lib.az_heads_forward if self.precision in ("bf16", "bf16r") else self.lib.az_heads_forward_f32
         rc = heads(self.board, B, P(feat), self.feat_stride, P(self.wp), P(self.bp), P(self.w1), P(self.b1),
                    P(self.w2), self.b2, P(logits), P(value), st)
         if rc != 0:
@@ -420,7 +462,7 @@ class FusedTowerEvaluator:
     def overflowed(self) -> bool:
         """f16x2 only: True when an activation left f16's range (|x| > 4,094) in any evaluation so far -- the results are then
         not to be trusted and the f32 tower must be used for this network.  Synchronises."""
-        return self.precision == "f16x2" and bool(int(self.overflow.item()))
+        return self.precision in ("f16x2", "f16") and bool(int(self.overflow.item()))
 
     def forward_static(self, x: torch.Tensor | None, logits: torch.Tensor, values: torch.Tensor, packed=None, n_boards: int = 0):
         """The same evaluation through az_tower_heads_forward_static: nothing is allocated -- not here (the caller owns

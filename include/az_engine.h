@@ -232,6 +232,24 @@ int az_augment_samples(az_engine *e, int32_t n, const float *states_dev, const f
 int az_read_stats(az_engine *e, az_stats *out, void *stream);
 int az_reset_stats(az_engine *e, void *stream);
 
+/* Row-tile tower (csrc/az_tower_h1.hip): the 15x15, 64-channel GomokuModel-family trunk (the network az_tower_forward
+ * evaluates; model contract nn_models/base.py:17-19, examples/gomoku/model.py:41-90) on the 16-bit MFMA pipe with one board
+ * row per cell tile -- no tap masks, no padding tile.  elem: AZ_H1_BF16 (bf16 operands, the arithmetic of az_tower_forward) or
+ * AZ_H1_F16 (f16 operands with az_tower_forward_h2's exact power-of-two scalings: 8x the precision at the same rate).
+ * Same inputs as az_tower_forward_f32; feature rows (n_boards, feat_stride) f32 for az_heads_forward_f32, or -- feat_bf16 != 0 --
+ * bf16 for az_heads_forward.  w0_dev / wl_dev:
+ * [tap 9][k-step][co tile 4][lane 64][8] 16-bit values of w * sw[layer]; bias_scaled_dev (1 + n_conv_layers, 64) f32 =
+ * bias * sw[layer] * SA, SA = 16 (f16) or 1 (bf16); sw_dev (1 + n_conv_layers) f32 powers of two (all 1 for bf16)
+ * (alphazero_amd.fused packs them).  overflow_dev (1) i32, may be NULL: set to 1 when an f16 activation exceeds the format's
+ * range (|x| > 4,094) -- results are then invalid and the caller must use another tower. */
+#define AZ_H1_F16 0
+#define AZ_H1_BF16 1
+int az_tower_forward_h1(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, int32_t elem,
+                        const float *x_f32_dev, const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev,
+                        const void *w0_dev, const void *wl_dev, const float *bias_scaled_dev, const float *sw_dev,
+                        const float *headw_dev, const float *headb_dev, void *feat_dev, int32_t feat_bf16, int32_t feat_stride,
+                        int32_t *overflow_dev, void *stream);
+
 /* EXPLORATORY, SECONDARY (csrc/az_tower_h2.hip): the 64-channel GomokuModel-family tower (the network az_tower_forward_f32
  * evaluates; model contract nn_models/base.py:17-19) at f32-LEVEL ACCURACY on the f16 MFMA pipe -- every f32 operand split
  * into two f16 halves (22 significant bits), w x = w1 x1 + w1 x2 + w2 x1 on v_mfma_f32_16x16x32_f16 with f32 accumulation.

@@ -98,11 +98,11 @@ def _tower_callback(ev, shape, dtype):
     return O.EVAL_FN(_cb), calls
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f32", "f32-quick", "bf16-quick", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16", "f32", "f32-quick", "bf16-quick", "f16x2", "bf16r", "f16"])
 def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     """engine + tower on the packed/flags path == oracle + the same tower as its evaluator ("f32-quick": the reference's
     QuickModel family, 128 channels, on the f32 tower's QuickModel instantiation -- config 5's network; "f16x2": the
-    split-operand tower of az_tower_h2.hip on an f32 engine)"""
+    split-operand tower of az_tower_h2.hip on an f32 engine; "bf16r" / "f16": the row-tile tower of az_tower_h1.hip, likewise)"""
     from alphazero_amd import Engine
     from alphazero_amd.arena import SelfPlayRunner
     from alphazero_amd.nets import GomokuNet, QuickNet
@@ -110,14 +110,14 @@ def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     n, G, sims = 15, 64, 100
     rng = np.random.default_rng(5)
     torch.manual_seed(3)
-    dtype = torch.bfloat16 if precision.startswith("bf16") else torch.float32
+    dtype = torch.bfloat16 if precision in ("bf16", "bf16-quick") else torch.float32  # (the towers asked for by name: f32 engine)
     net = _randomised(QuickNet(n, 9, 128, 2, 3) if precision.endswith("quick") else GomokuNet(n, 64, 2)).eval().cuda().to(dtype)
     eng = Engine(2, G, sims, board_size=n, nn_dtype=dtype, device="cuda:0")
     A = eng.dims.n_action
     pos = _positions(oracle, G, rng, n)
     for g, (h, p) in enumerate(pos):
         eng.set_position(g, h, p)
-    run = SelfPlayRunner(eng, net, sims, fused="f16x2" if precision == "f16x2" else True)
+    run = SelfPlayRunner(eng, net, sims, fused=precision if precision in ("f16x2", "bf16r", "f16") else True)
     assert run.fused is not None and run.fused.precision == precision.split("-")[0]
     noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
     _fix_noise(run, noise_np)

@@ -1,0 +1,126 @@
+"""az_tower_h1.hip (precisions "bf16r" and "f16"): the 15x15 / 64-channel GomokuModel-family tower with one board row per cell
+tile.  Floating point -- a throughput-mode evaluator, not the reference's f32 arithmetic (nn_models/base.py:17-19): "bf16r" is
+held to the bf16 tower's own bars (tests/test_gpu_tower.py: max |dlogit| <= 3 % of the logit scale + 0.02, mean <= 0.4 % + 0.002
+against the fp32 forward); "f16" (11 significant bits instead of 8, exact power-of-two scalings) to an eighth of them.  Both are
+deterministic per board, and the engine's packed leaf batch + flags gives the dense planes' rows bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from .test_gpu_tower import _randomised
+
+pytestmark = pytest.mark.gpu
+
+BARS = {"bf16r": (0.03, 0.02, 0.004, 0.002, 0.03), "f16": (0.004, 0.0025, 0.0005, 0.00025, 0.004)}
+
+
+@pytest.mark.parametrize("precision", ["bf16r", "f16"])
+@pytest.mark.parametrize("blocks,batch", [(2, 64), (2, 1100), (3, 33), (0, 5), (10, 600), (1, 4096)])
+def test_row_tile_tower_matches_fp32_forward(precision, blocks, batch):
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(0)
+    net = _randomised(GomokuNet(15, 64, blocks)).eval().cuda()
+    ev = FusedTowerEvaluator(net, precision)
+    x = torch.randint(-1, 2, (batch, 9, 15, 15), device="cuda").float()
+    x[:, 8] = torch.where(torch.rand(batch, 1, 1, device="cuda") < 0.5, -1.0, 1.0)
+    with torch.inference_mode():
+        ref_p, ref_v = net(x)
+    p, v = ev(x.contiguous())
+    p, v = p.clone(), v.clone()
+    assert not ev.overflowed()
+    scale = float(ref_p.abs().max())
+    a_max, b_max, a_mean, b_mean, v_bar = BARS[precision]
+    err, mean = float((p - ref_p).abs().max()), float((p - ref_p).abs().mean())
+    print(f"{precision}: max |dlogit| {err:.3e}, mean {mean:.3e} at logit scale {scale:.3f}")
+    assert err <= a_max * scale + b_max, (err, scale)
+    assert mean <= a_mean * scale + b_mean, (mean, scale)
+    assert float((v - ref_v).abs().max()) <= v_bar
+    # deterministic per board: a permuted batch gives the same rows bit for bit
+    perm = torch.randperm(batch, device="cuda")
+    p2, v2 = ev(x[perm].contiguous())
+    assert torch.equal(p2, p[perm]) and torch.equal(v2, v[perm])
+
+
+def test_f16_is_several_times_closer_to_f32_than_bf16():
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(1)
+    net = _randomised(GomokuNet(15, 64, 2)).eval().cuda()
+    x = torch.randint(-1, 2, (512, 9, 15, 15), device="cuda").float().contiguous()
+    with torch.inference_mode():
+        ref_p, _ = net.double()(x.double())
+    net.float()
+    errs = {}
+    for prec in ("f16", "bf16r"):
+        p, _ = FusedTowerEvaluator(net, prec)(x)
+        errs[prec] = float((p.double() - ref_p).abs().mean())
+    assert errs["f16"] * 4.0 <= errs["bf16r"], errs
+
+
+@pytest.mark.parametrize("precision", ["bf16r", "f16"])
+@pytest.mark.parametrize("blocks,G", [(2, 2100), (0, 700)])
+def test_row_tile_tower_packed_flags_equals_dense(precision, blocks, G):
+    """the engine's packed leaf batch + needs-the-network flags == the dense planes of the same positions, bit for bit, for every
+    flag pattern (rows that are off are not compared: the heads kernel computes them from stale feature rows); G > 512 workgroups x 2: every workgroup draws several tickets, so
+    the one-board-ahead hand-over (flag skip, parked packed input) is exercised"""
+    from alphazero_amd import Engine
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(3)
+    net = _randomised(GomokuNet(15, 64, blocks)).eval().cuda()
+    ev = FusedTowerEvaluator(net, precision)
+    eng = Engine(2, G, 8, board_size=15, nn_dtype=torch.float32, device="cuda:0")
+    A = eng.dims.n_action
+    nn, lg, vl = eng.new_nn_input(), eng.new(G, A), eng.new(G)
+    it = torch.ones(G, device="cuda")
+    for _ in range(6):  # a few plies so that the boards differ
+        eng.begin_search()
+        for _ in range(3):
+            eng.select_gather(nn)
+            eng.eval_hash(nn, lg, vl, 6.0)
+            eng.expand_backup(lg, vl, None)
+        eng.play_moves(it, torch.empty(G, A, device="cuda").exponential_(1))
+    eng.begin_search()
+    eng.select_gather(nn)  # dense planes + packed ring of the same leaves
+    pd, vd = ev(nn.contiguous())
+    pd, vd = pd.clone(), vd.view(-1).clone()
+    ring, leaf, _, _, flags = eng.leaf_buffers()
+    gen = torch.Generator().manual_seed(1)
+    for name, fl in {"all": torch.ones(G, dtype=torch.uint8), "half": (torch.rand(G, generator=gen) < 0.5).to(torch.uint8),
+                     "sparse": (torch.rand(G, generator=gen) < 0.03).to(torch.uint8), "none": torch.zeros(G, dtype=torch.uint8),
+                     "runs": ((torch.arange(G) // 37) % 2).to(torch.uint8)}.items():
+        flg = fl.cuda()
+        logits = torch.full((G, A), 77.0, device="cuda")
+        _, v = ev(None, logits_out=logits, packed=(ring, leaf, None, None, flg.data_ptr()), n_boards=G)
+        v = v.view(-1).clone()
+        torch.cuda.synchronize()
+        on = flg.bool()
+        assert torch.equal(logits[on], pd[on]), name
+        assert torch.equal(v[on], vd[on]), name
+    eng.close()
+
+
+def test_row_tile_tower_limits_and_overflow_flag():
+    from alphazero_amd.engine import EngineError
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet, QuickNet
+
+    torch.manual_seed(1)
+    net = _randomised(GomokuNet(15, 64, 1)).eval().cuda()
+    with torch.no_grad():
+        net._shared_layers[1].weight.mul_(3.0e4)  # blow the stem's outputs far past 4,094
+    ev = FusedTowerEvaluator(net, "f16")
+    x = torch.randint(-1, 2, (8, 9, 15, 15), device="cuda").float()
+    ev(x.contiguous())
+    assert ev.overflowed()
+    for prec in ("f16", "bf16r"):
+        with pytest.raises(EngineError):
+            FusedTowerEvaluator(GomokuNet(9, 64, 1).eval().cuda(), prec)  # 15x15 only
+        with pytest.raises(EngineError):
+            FusedTowerEvaluator(GomokuNet(15, 128, 1).eval().cuda(), prec)
+        with pytest.raises(EngineError):
+            FusedTowerEvaluator(QuickNet(15, 9, 64, 1, 2).eval().cuda(), prec)
