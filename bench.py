@@ -516,7 +516,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     out = {
         "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"bf16r": "bf16", "f16r": "f16"}.get(dtype_name, dtype_name), "data": "synthetic",
         "config": {"workload": f"{args.workload}: {sims} sims/move, {slots} concurrent games per GPU, "
                                f"evaluator={evaluator} ({dtype_name} network arithmetic), one step = one self-play move of every game",
                    "slots_per_gpu": slots, "sims_per_move": sims, "parallelism": f"games sharded x{world}, no data-path collective",
@@ -563,10 +564,11 @@ def decision_agreement(args, dev, n_pos=1024, plies=12, other="bf16"):
     torch.cuda.manual_seed(99)
     res, pos_moves = {}, None
     noise = expo = None
+    named = {"f16x2": "f16x2", "f16r": "f16", "bf16r": "bf16r"}  # towers asked for by name on an f32 engine
     for name, dt in (("f32", torch.float32), (other, torch.bfloat16 if other == "bf16" else torch.float32)):
         model = make_model(args.workload).to(dev).to(dt)
         eng = Engine(game, n_pos, sims, board_size=n, nn_dtype=dt, device=dev)
-        run = SelfPlayRunner(eng, model, sims, fused=(True if name != "f16x2" else "f16x2"))
+        run = SelfPlayRunner(eng, model, sims, fused=named.get(name, True))
         A = eng.dims.n_action
         it = torch.ones(n_pos, device=dev)
         if pos_moves is None:  # the opening moves, played once (hash evaluator, 8 sims) and replayed for the other precision
@@ -611,7 +613,7 @@ def decision_agreement(args, dev, n_pos=1024, plies=12, other="bf16"):
             "identical_visit_vectors": float((v32 == v16).all(1)[live].sum()) / nl,
             "mean_abs_pi_difference": float(((v32.float() - v16.float()).abs().sum(1) / max(sims - 1, 1))[live].mean()) / 2,
             "how": f"{nl} positions {plies} plies into a game, same Dirichlet and exponential rows, full search with the f32 tower "
-                   f"(az_tower_f32.hip) and with the {other} tower ({'az_tower.hip' if other == 'bf16' else 'az_tower_h2.hip'}); mean_abs_pi_difference = total variation "
+                   f"(az_tower_f32.hip) and with the {other} tower ({'az_tower.hip' if other == 'bf16' else 'az_tower_h2.hip' if other == 'f16x2' else 'az_tower_h1.hip'}); mean_abs_pi_difference = total variation "
                    "distance between the two root visit distributions"}
 
 
@@ -817,9 +819,13 @@ def main():
         primary = "f32"  # the reference's own arithmetic; every workload has an f32 evaluator (hand-written tower or the module's forward)
     out = measure(args, primary, args.steps, args.warmup, dev, rank, world, dst)
     sec_steps = args.secondary_steps if args.secondary_steps >= 0 else (min(args.steps, 4) if world == 1 else 0)
-    second = None
+    second = second_f16 = None
+    row_tile = False
     if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1:
-        second = measure(args, "bf16", sec_steps, 1, dev, rank, world, dst)
+        # the 15x15 / 64-channel GomokuModel network: the row-tile tower (az_tower_h1.hip), bf16 operands like az_tower.hip's
+        row_tile = args.workload in ("gomoku15", "gomoku15_deep64")
+        second = measure(args, "bf16r" if row_tile else "bf16", sec_steps, 1, dev, rank, world, dst)
+        second_f16 = measure(args, "f16r", sec_steps, 1, dev, rank, world, dst, with_probe=False) if row_tile else None
     third = None
     if primary == "f32" and sec_steps > 0 and args.workload in ("gomoku15", "gomoku9", "gomoku15_deep64") and args.evaluator in ("auto", "fused") \
             and args.leaves <= 1:
@@ -836,7 +842,15 @@ def main():
             if cpu:
                 second["speedup_vs_cpu_baseline_f32_network"] = second["value"] / cpu["value"]
             if not args.no_agreement:
-                second["decision_agreement"] = decision_agreement(args, dev)
+                second["decision_agreement"] = decision_agreement(args, dev, other="bf16r" if row_tile else "bf16")
+            if second_f16 is not None:  # the same kernel on f16 operands (exact power-of-two scalings): 8x the operand precision
+                r16 = second_f16["roofline"]
+                second["f16_operands"] = {
+                    "value": second_f16["value"], "unit": "sims/s", "ms_per_step": second_f16["ms_per_step"], "dtype": "f16",
+                    "roofline": {k: r16[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "ms_per_launch", "boards_per_launch")},
+                    "note": "az_tower_h1.hip with f16 operands (activations x 16, weights x a power of two per layer, f32 accumulation) "
+                            "and the f32 heads: the throughput mode for callers who want its decisions closer to the f32 search's",
+                    "decision_agreement": None if args.no_agreement else decision_agreement(args, dev, other="f16r")}
             out["throughput_mode"] = second
         if third is not None:
             third["note"] = ("EXPLORATORY, secondary: the same workload with az_tower_h2.hip -- every f32 operand of the convolutions split into two f16 "

@@ -16,14 +16,30 @@ if __name__ == "__main__":
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import GomokuNet
 
+    from alphazero_amd import Engine
+
     prec = sys.argv[1] if len(sys.argv) > 1 else "bf16r"
     B = 16384
     torch.manual_seed(0)
     net = GomokuNet(15, 64, 2).eval().cuda()
-    x = torch.randint(-1, 2, (B, 9, 15, 15), device="cuda").float().contiguous()
     ev = FusedTowerEvaluator(net, prec)
+    # the engine's packed leaf batch after a few plies (the path the bench times), every slot flagged
+    eng = Engine(2, B, 8, board_size=15, nn_dtype=torch.float32, device="cuda:0")
+    A = eng.dims.n_action
+    lg, vl = eng.new(B, A), eng.new(B)
+    it = torch.ones(B, device="cuda")
+    for _ in range(8):
+        eng.begin_search()
+        for _ in range(3):
+            eng.select_gather(None)
+            eng.eval_hash(None, lg, vl, 6.0)
+            eng.expand_backup(lg, vl, None)
+        eng.play_moves(it, torch.empty(B, A, device="cuda").exponential_(1))
+    eng.begin_search()
+    eng.select_gather(None)
+    ring, leaf, _, _, flags = eng.leaf_buffers()
     for _ in range(20):
-        ev(x)
+        ev(None, logits_out=lg, packed=(ring, leaf, None, None, flags), n_boards=B)
     torch.cuda.synchronize()
     lib = load_library()
     buf = np.zeros(512 * 4 * 32, dtype=np.uint64)

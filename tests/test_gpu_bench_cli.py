@@ -44,6 +44,17 @@ def test_bench_line_gomoku_f32_primary_with_bf16_beside_it_under_rccl():
     assert h["roofline"]["f32_equivalent_tflops"] > 0 and h["decision_agreement"]["same_most_visited_move"] >= 0.9
 
 
+def test_bench_line_gomoku15_throughput_mode_is_the_row_tile_tower():
+    d = _run(["--workload", "gomoku15", "--slots", "128", "--sims", "12", "--no-cpu-baseline"])
+    assert d["dtype"] == "f32" and d["roofline"]["kernel"] == "k_tower_f32_t16"
+    t = d["throughput_mode"]
+    assert t["dtype"] == "bf16" and t["roofline"]["kernel"] == "k_tower_h1" and "az_tower_h1.hip" in t["nn_eval"]["implementation"]
+    assert t["decision_agreement"]["same_most_visited_move"] >= 0.5
+    f = t["f16_operands"]  # the same kernel on f16 operands: closer to the f32 search
+    assert f["dtype"] == "f16" and f["value"] > 0 and f["roofline"]["kernel"] == "k_tower_h1"
+    assert f["decision_agreement"]["same_most_visited_move"] >= t["decision_agreement"]["same_most_visited_move"] - 0.05
+
+
 def test_bench_line_small_game_fused_and_through_pytorch():
     base = ["--workload", "dab", "--slots", "128", "--sims", "16", "--graph", "1", "--no-cpu-baseline"]
     d = _run(base)  # auto: the one-kernel f32 network of az_smallnet.hip
