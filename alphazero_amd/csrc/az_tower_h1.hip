@@ -26,6 +26,7 @@
 
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 #include "../../include/az_engine.h"
 
@@ -343,9 +344,12 @@ __global__ __launch_bounds__(256, 2) void k_tower_h1(const float *__restrict__ x
     // channels.  with_res: the activations being overwritten are the block's residual: read them first and start the NEXT
     // layer's accumulators at (bias + residual) x SW_next x SA.  (The pad lane reads and writes its dump region.)
     auto epilogue = [&](int layer, bool with_res) {
-      const float inv = E::SCALED ? tab[layer * (C + 4) + C] : 1.0f;
-      const float swn = (E::SCALED && with_res) ? tab[(layer + 1) * (C + 4) + C + 1] : 1.0f;
-      const f2 inv2 = {inv, inv};
+      // (wave-uniform, read as scalars: the layers whose scales are all 1 -- every layer of a bf16 tower, and of an f16 tower
+      // unless its weights are tiny -- take the branch without the multiplies)
+      const float inv = E::SCALED ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tab[layer * (C + 4) + C]))) : 1.0f;
+      const float swn = (E::SCALED && with_res)
+                            ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tab[(layer + 1) * (C + 4) + C + 1])))
+                            : 1.0f;
       // Branch-free over all eight tile slots: a wave of the odd half has no tile 7 -- its slot 7 holds whatever, reads and
       // writes the dump region (ol7) and stays out of the overflow maximum.  Every residual read stands before the first
       // store (the compiler cannot tell that they do not alias).
@@ -355,40 +359,46 @@ __global__ __launch_bounds__(256, 2) void k_tower_h1(const float *__restrict__ x
         for (int pt = 0; pt < TPW; ++pt) xr[pt] = *(const v8 *)(pt < TPW - 1 ? ol + pt * 16 * PITCH : ol7);
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int pt = 0; pt < TPW; ++pt) {
-        v2 o[4];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          f2 y01 = {acc[pt][ct][0], acc[pt][ct][1]}, y23 = {acc[pt][ct][2], acc[pt][ct][3]};
-          if (E::SCALED) { y01 *= inv2; y23 *= inv2; }
-          o[2 * ct] = E::cvt_relu(y01);
-          o[2 * ct + 1] = E::cvt_relu(y23);
-          if (pt < TPW - 1) mx = E::vmax(E::vmax(mx, o[2 * ct]), o[2 * ct + 1]);
-          else mx7 = E::vmax(E::vmax(mx7, o[2 * ct]), o[2 * ct + 1]);
-        }
-        *(v8 *)(pt < TPW - 1 ? ol + pt * 16 * PITCH : ol7) = (v8){o[0][0], o[0][1], o[1][0], o[1][1], o[2][0], o[2][1], o[3][0], o[3][1]};
-        __builtin_amdgcn_sched_barrier(0);  // tile by tile: scaled copies of all 64 accumulators at once would spill
-      }
-      if (with_res) {  // acc of the block's second conv = bias + residual x SW_next: one selector MFMA per tile and channel tile
-        const f4 bn0 = *(const f4 *)(tab + (layer + 1) * (C + 4) + 32 * cg + 8 * kg);
-        const f4 bn1 = *(const f4 *)(tab + (layer + 1) * (C + 4) + 32 * cg + 8 * kg + 4);
-        v8 p0 = *(const v8 *)(pfr + lane * 16), p1 = *(const v8 *)(pfr + 1024 + lane * 16);
-        if (E::SCALED) {
-          const T s = (T)swn;  // (a power of two <= 2^15: the host caps the f16 scales there)
-          p0 *= s;
-          p1 *= s;
-        }
+      auto body = [&](auto unit_c) {
+        constexpr bool UNIT = decltype(unit_c)::value;
+        const f2 inv2 = {inv, inv};
 #pragma unroll
         for (int pt = 0; pt < TPW; ++pt) {
-          acc[pt][0] = E::mfma(p0, xr[pt], bn0);
-          acc[pt][1] = E::mfma(p1, xr[pt], bn1);
-        }
-        // finished HERE (an empty asm the optimiser must assume reads them): sunk into the next conv layer's first step they
-        // doubled its accumulator registers and spilled
+          v2 o[4];
 #pragma unroll
-        for (int pt = 0; pt < TPW; ++pt) asm volatile("" : "+v"(acc[pt][0]), "+v"(acc[pt][1]));
-      }
+          for (int ct = 0; ct < 2; ++ct) {
+            f2 y01 = {acc[pt][ct][0], acc[pt][ct][1]}, y23 = {acc[pt][ct][2], acc[pt][ct][3]};
+            if (!UNIT) { y01 *= inv2; y23 *= inv2; }
+            o[2 * ct] = E::cvt_relu(y01);
+            o[2 * ct + 1] = E::cvt_relu(y23);
+            if (pt < TPW - 1) mx = E::vmax(E::vmax(mx, o[2 * ct]), o[2 * ct + 1]);
+            else mx7 = E::vmax(E::vmax(mx7, o[2 * ct]), o[2 * ct + 1]);
+          }
+          *(v8 *)(pt < TPW - 1 ? ol + pt * 16 * PITCH : ol7) = (v8){o[0][0], o[0][1], o[1][0], o[1][1], o[2][0], o[2][1], o[3][0], o[3][1]};
+          __builtin_amdgcn_sched_barrier(0);  // tile by tile: scaled copies of all 64 accumulators at once would spill
+        }
+        if (with_res) {  // acc of the block's second conv = bias + residual x SW_next: one selector MFMA per tile and channel tile
+          const f4 bn0 = *(const f4 *)(tab + (layer + 1) * (C + 4) + 32 * cg + 8 * kg);
+          const f4 bn1 = *(const f4 *)(tab + (layer + 1) * (C + 4) + 32 * cg + 8 * kg + 4);
+          v8 p0 = *(const v8 *)(pfr + lane * 16), p1 = *(const v8 *)(pfr + 1024 + lane * 16);
+          if (!UNIT) {
+            const T s = (T)swn;  // (a power of two <= 2^15: the host caps the f16 scales there)
+            p0 *= s;
+            p1 *= s;
+          }
+#pragma unroll
+          for (int pt = 0; pt < TPW; ++pt) {
+            acc[pt][0] = E::mfma(p0, xr[pt], bn0);
+            acc[pt][1] = E::mfma(p1, xr[pt], bn1);
+          }
+          // finished HERE (an empty asm the optimiser must assume reads them): sunk into the next conv layer's first step they
+          // doubled its accumulator registers and spilled
+#pragma unroll
+          for (int pt = 0; pt < TPW; ++pt) asm volatile("" : "+v"(acc[pt][0]), "+v"(acc[pt][1]));
+        }
+      };
+      if (!E::SCALED || (inv == 1.0f && swn == 1.0f)) body(std::true_type{});
+      else body(std::false_type{});
     };
 
     // ---- stem

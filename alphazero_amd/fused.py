@@ -319,8 +319,11 @@ class FusedTowerEvaluator:
         h1 = self.precision in ("f16", "bf16r")  # the row-tile tower: one 16-bit product, f16 scaled like f16x2 or plain bf16
         h2 = self.precision == "f16x2" or h1
         h1_dtype = torch.bfloat16 if self.precision == "bf16r" else torch.float16
-        # (the row-tile tower's f16 scales stop at 2^15: the next layer's scale rides on an f16 operand of the residual MFMA)
-        scale_of = (lambda w: 1.0) if self.precision == "bf16r" else (lambda w: min(_h2_scale(w), 32768.0)) if h1 else _h2_scale
+        # (the row-tile tower's f16 scales stop at 2^15 -- the next layer's scale rides on an f16 operand of the residual MFMA --
+        # and are 1 unless a layer's weights are tiny (max |w| < 2^-6): one f16 product does not need its small operands lifted
+        # the way the split halves of f16x2 do, and a layer at scale 1 skips the epilogue's multiplies)
+        scale_of = ((lambda w: 1.0) if self.precision == "bf16r" else
+                    (lambda w: 1.0 if float(w.abs().max()) >= 2.0 ** -6 else min(_h2_scale(w), 32768.0)) if h1 else _h2_scale)
         pack_h = (lambda w, cin, sc: _pack3x3_h1(w, cin, sc, h1_dtype)) if h1 else _pack3x3_h2
         pack3 = _pack3x3_f32 if self.precision == "f32" else _pack3x3
         w, b = _fold(sl[0], sl[1])

@@ -60,6 +60,33 @@ def test_f16_is_several_times_closer_to_f32_than_bf16():
     assert errs["f16"] * 4.0 <= errs["bf16r"], errs
 
 
+def test_f16_layers_with_tiny_weights_take_the_scaled_path():
+    """a layer whose folded weights are all below 2^-6 is packed x a power of two (fused.py) and its epilogue, and the residual
+    selector of the block it closes, undo that scale: same bars, and the scales really are not 1"""
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(4)
+    net = _randomised(GomokuNet(15, 64, 3)).eval().cuda()
+    with torch.no_grad():
+        blocks = list(net._shared_layers)[3:]
+        blocks[0]._conv2.weight.mul_(2.0 ** -9)   # the closing conv of a block: its scale rides on the residual selector
+        blocks[1]._conv1.weight.mul_(2.0 ** -8)
+        blocks[2]._conv1.weight.mul_(2.0 ** 3)
+    ev = FusedTowerEvaluator(net, "f16")
+    assert sorted(set(ev.sw.cpu().tolist())) != [1.0]
+    x = torch.randint(-1, 2, (300, 9, 15, 15), device="cuda").float().contiguous()
+    with torch.inference_mode():
+        ref_p, ref_v = net(x)
+    p, v = ev(x)
+    assert not ev.overflowed()
+    scale = float(ref_p.abs().max())
+    a_max, b_max, a_mean, b_mean, v_bar = BARS["f16"]
+    assert float((p - ref_p).abs().max()) <= a_max * scale + b_max
+    assert float((p - ref_p).abs().mean()) <= a_mean * scale + b_mean
+    assert float((v - ref_v).abs().max()) <= v_bar
+
+
 @pytest.mark.parametrize("precision", ["bf16r", "f16"])
 @pytest.mark.parametrize("blocks,G", [(2, 2100), (0, 700)])
 def test_row_tile_tower_packed_flags_equals_dense(precision, blocks, G):
