@@ -99,10 +99,13 @@ class SelfPlayRunner:
                     raise EngineError("the fused evaluator exists in bf16 and f32: create the engine with one of these nn_dtypes")
                 # the engine's nn_dtype decides: f32 = the reference's own arithmetic (az_tower_f32.hip), bf16 = throughput mode;
                 # fused="f16x2" (f32 engine): az_tower_h2.hip, f32-level accuracy on the f16 MFMA pipe (secondary, by name only);
-                # fused="f16" / "bf16r" (f32 engine, 15x15): az_tower_h1.hip, the row-tile tower with one 16-bit product
+                # fused="f16" / "bf16r" (15x15): az_tower_h1.hip, the row-tile tower with one 16-bit product -- "bf16r" is also what
+                # fused=True picks on a bf16 engine when the network fits it
                 prec = "f32" if engine.nn_dtype == torch.float32 else "bf16"
+                if prec == "bf16" and not isinstance(fused, str) and FusedTowerEvaluator.row_tile_supports(model):
+                    prec = "bf16r"  # the same arithmetic on the row-tile tower (the runner feeds the packed batch: no dense dtype involved)
                 if isinstance(fused, str):
-                    if fused not in ("f32", "bf16", "f16x2", "f16", "bf16r") or (fused == "bf16") != (prec == "bf16"):
+                    if fused not in ("f32", "bf16", "f16x2", "f16", "bf16r") or (fused in ("f32", "bf16") and fused != prec.rstrip("r")):
                         raise EngineError(f"fused={fused!r} does not fit an engine with nn_dtype {engine.nn_dtype}")
                     prec = fused
                 self.fused = FusedTowerEvaluator(model, prec)

@@ -215,10 +215,17 @@ class FusedTowerEvaluator:
         ch, n_layers = model._shared_layers[0].out_channels, 2 * (len(model._shared_layers) - 3)
         return "f32" if ch == 64 or n_layers <= 40 else None  # (128 channels: the 16-cell-tile kernel only, bias table of 40 layers)
 
+    @classmethod
+    def row_tile_supports(cls, model: nn.Module) -> bool:
+        """the row-tile tower (csrc/az_tower_h1.hip; precisions "bf16r", "f16"): 64-channel GomokuModel family on 15x15"""
+        return (cls.supports(model) and cls.quick_shape(model) is None and model._shared_layers[0].out_channels == 64
+                and model._policy_head[4].in_features == 225)
+
     def __init__(self, model: nn.Module, precision: str = "bf16"):
-        """precision: "bf16" (az_tower.hip: bf16 operands, f32 accumulation -- the throughput mode) or "f32"
-        (az_tower_f32.hip: f32 MFMA, the reference's own arithmetic).  The weights are folded and
-        packed from the module's parameters in f32 either way, whatever dtype the module itself holds."""
+        """precision: "bf16" (az_tower.hip: bf16 operands, f32 accumulation -- the throughput mode), "f32"
+        (az_tower_f32.hip: f32 MFMA, the reference's own arithmetic), "bf16r" / "f16" (az_tower_h1.hip, 15x15 / 64 channels:
+        the faster throughput-mode tower, bf16 or f16 operands; dense input is f32) or "f16x2" (az_tower_h2.hip).  The
+        weights are folded and packed from the module's parameters in f32 either way, whatever dtype the module itself holds."""
         if not self.supports(model):
             raise EngineError("FusedTowerEvaluator: not a GomokuModel- or QuickModel-family network (64- or 128-channel 3x3 residual tower)")
         self.lib = load_library()

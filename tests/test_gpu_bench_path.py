@@ -89,7 +89,7 @@ def _tower_callback(ev, shape, dtype):
 
     def _cb(_ctx, x, n_in, logits, n_action, value):
         arr = np.ctypeslib.as_array(x, shape=(n_in,))
-        xt = torch.from_numpy(arr.copy()).view(1, cin, h, w).cuda().to(dtype).contiguous()
+        xt = torch.from_numpy(arr.copy()).view(1, cin, h, w).cuda().to(getattr(ev, "in_dtype", dtype)).contiguous()  # (the tower's own dense dtype)
         p, v = ev(xt)
         np.ctypeslib.as_array(logits, shape=(n_action,))[:] = p.reshape(-1).cpu().numpy()
         value[0] = float(v.reshape(-1)[0].item())
@@ -117,7 +117,8 @@ def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     pos = _positions(oracle, G, rng, n)
     for g, (h, p) in enumerate(pos):
         eng.set_position(g, h, p)
-    run = SelfPlayRunner(eng, net, sims, fused=precision if precision in ("f16x2", "bf16r", "f16") else True)
+    # ("bf16" by name: az_tower.hip -- left to itself the runner picks the row-tile tower for this network on a bf16 engine)
+    run = SelfPlayRunner(eng, net, sims, fused=precision if precision in ("f16x2", "bf16r", "f16", "bf16") else True)
     assert run.fused is not None and run.fused.precision == precision.split("-")[0]
     noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
     _fix_noise(run, noise_np)
@@ -132,6 +133,23 @@ def test_runner_search_fused_tower_matches_oracle(oracle, precision):
         assert np.array_equal(q[g], r["child_q"]), g
         assert np.array_equal(prior[g], r["root_prior"]), g
     assert calls[0] == eng.read_stats()["evals"]
+
+
+def test_runner_picks_the_row_tile_tower_for_a_bf16_engine_on_15x15():
+    from alphazero_amd import Engine
+    from alphazero_amd.arena import SelfPlayRunner
+    from alphazero_amd.nets import GomokuNet
+
+    for n, want in ((15, "bf16r"), (9, "bf16")):
+        eng = Engine(2, 8, 4, board_size=n, nn_dtype=torch.bfloat16, device="cuda:0")
+        run = SelfPlayRunner(eng, GomokuNet(n, 64, 1).eval().cuda().bfloat16(), 4, fused=True)
+        assert run.fused.precision == want
+        run.search()
+        eng.check()
+        eng.close()
+    eng = Engine(2, 8, 4, board_size=15, nn_dtype=torch.bfloat16, device="cuda:0")
+    assert SelfPlayRunner(eng, GomokuNet(15, 128, 1).eval().cuda().bfloat16(), 4, fused=True).fused.precision == "bf16"
+    eng.close()
 
 
 @pytest.mark.parametrize("kind", ["gomokunet-bf16", "quicknet-f32", "quicknet-bf16"])
