@@ -354,11 +354,14 @@ class ChessArena:
         eng.reset_games(None)
         finished = samples = 0
         put_batch = getattr(experience_pool, "put_batch", None)
+        ring_writer = None
         if put_batch is None:
             from .samples import SharedRingWriter
 
-            if SharedRingWriter.accepts(experience_pool):  # the reference's shared-memory ring: written in bulk (8x augmented)
-                put_batch = SharedRingWriter(experience_pool, eng).put_batch
+            # the reference's shared-memory ring: written in bulk, augmented on the GPU as its own config switches say, straight
+            # from the device tensors (one device-to-host copy of the finished rows, none of the raw samples)
+            if SharedRingWriter.accepts(experience_pool):
+                ring_writer = SharedRingWriter(experience_pool, eng)
         while finished < n_games:
             acts, done = run.move_round(inv_tao)
             done_h = done.cpu()
@@ -374,15 +377,18 @@ class ChessArena:
             if trace is not None:  # which games these are, and how many samples each one puts (in this order)
                 trace[-1]["finished_ids"], trace[-1]["finished_plies"] = ids_h[idx].tolist(), plies_h.tolist()
             states, pis, zs, offs = eng.emit_samples(idx.to(torch.int32), plies_h)
-            states_h = states.view(-1, d.nn_channels, d.height, d.width).cpu()
-            pis_h, zs_h = pis.cpu(), zs.cpu()
-            if put_batch is not None:
-                put_batch(states_h, pis_h, zs_h)
-            else:
-                for k in range(states_h.shape[0]):
-                    experience_pool.put_tupule_experience(
-                        (states_h[k:k + 1].clone(), pis_h[k:k + 1].clone(), zs_h[k:k + 1].clone()))
-            samples += int(states_h.shape[0])
+            if ring_writer is not None:
+                ring_writer.put_batch(states, pis, zs)
+            else:  # host tensors, as the reference's pools take them
+                states_h = states.view(-1, d.nn_channels, d.height, d.width).cpu()
+                pis_h, zs_h = pis.cpu(), zs.cpu()
+                if put_batch is not None:
+                    put_batch(states_h, pis_h, zs_h)
+                else:
+                    for k in range(states_h.shape[0]):
+                        experience_pool.put_tupule_experience(
+                            (states_h[k:k + 1].clone(), pis_h[k:k + 1].clone(), zs_h[k:k + 1].clone()))
+            samples += int(states.shape[0])
             finished += int(idx.numel())
             # restart finished slots while games remain (slot recycling)
             restart = torch.zeros(slots, dtype=torch.uint8)

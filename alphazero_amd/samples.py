@@ -157,11 +157,33 @@ class SharedRingWriter:
     ``Engine.emit_samples`` (device or host; put order).  ``ChessArena.self_play_many`` builds one by itself when it is
     handed such a pool."""
 
-    def __init__(self, pool, engine, augment: bool = True):
+    # which of the 8 rows az_augment_samples writes per sample (rot90 k, then its flip, k = 0..3) the reference's enhancer
+    # returns under its config switches (utils/data_enhancer.py:29-45): rotation + flip: all; rotation only: the four rotations;
+    # flip only: the flipped sample ALONE (the reference does not keep the original there); enhancement off: the sample itself
+    ROWS = {"rot+flip": (0, 1, 2, 3, 4, 5, 6, 7), "rot": (0, 2, 4, 6), "flip": (1,), "none": (0,)}
+
+    @staticmethod
+    def mode_of(pool) -> str:
+        """the augmentation the pool's own ``put_tupule_experience`` would apply: the config switches its module imported
+        (utils/share_ring_buffer.py:119-127 reads USE_DATA_ENHANCEMENT; the enhancer USE_ROATATION / USE_FLIP,
+        config/utils_config.py:27-55); 8-fold when the module does not say"""
+        import sys
+
+        mod = sys.modules.get(type(pool).__module__)
+        if not bool(getattr(mod, "USE_DATA_ENHANCEMENT", True)):
+            return "none"
+        rot, flip = bool(getattr(mod, "USE_ROATATION", True)), bool(getattr(mod, "USE_FLIP", True))
+        return "rot+flip" if rot and flip else "rot" if rot else "flip" if flip else "none"
+
+    def __init__(self, pool, engine, augment=None):
+        """augment: None = as the pool's own config says (mode_of), True = 8-fold, False = none, or one of ROWS' keys"""
         for name in ("_states", "_prior", "_values", "_write_idx", "_read_idx", "_size", "_total_written", "_lock", "_not_empty"):
             if not hasattr(pool, name):
                 raise TypeError(f"not a SharedRingBufferExperiencePool-like object: no attribute {name}")
-        self.pool, self.e, self.augment = pool, engine, augment
+        self.mode = self.mode_of(pool) if augment is None else ("rot+flip" if augment is True else "none" if augment is False else str(augment))
+        if self.mode not in self.ROWS:
+            raise ValueError(f"augment: one of {sorted(self.ROWS)}")
+        self.pool, self.e, self.augment = pool, engine, self.mode != "none"
         self.capacity = int(pool._states.shape[0])
         d = engine.dims
         if pool._states[0].numel() != d.nn_numel or pool._prior[0].numel() != d.n_action:
@@ -173,7 +195,8 @@ class SharedRingWriter:
                                                "_total_written", "_lock", "_not_empty"))
 
     def put_batch(self, states, pis, zs) -> int:
-        """-> rows written (8 per position with augmentation)"""
+        """states / pis / zs: device tensors (no copy; what ChessArena.self_play_many hands over) or host tensors.
+        -> rows written (8 per position with the full augmentation)"""
         dev = self.e.device
         n = int(states.shape[0])
         if n == 0:
@@ -183,6 +206,9 @@ class SharedRingWriter:
         zs = zs.reshape(n).to(dev, torch.float32).contiguous()
         if self.augment:
             states, pis, zs = self.e.augment_samples(states, pis, zs)
+            if self.mode != "rot+flip":  # the subset of the 8 the reference's switches leave, in its order
+                sel = (8 * torch.arange(n, device=dev).view(-1, 1) + torch.tensor(self.ROWS[self.mode], device=dev).view(1, -1)).reshape(-1)
+                states, pis, zs = states[sel], pis[sel], zs[sel]
         rows = int(states.shape[0])
         s_h, p_h, z_h = states.cpu(), pis.cpu(), zs.cpu()
         p, cap = self.pool, self.capacity

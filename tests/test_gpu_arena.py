@@ -446,6 +446,44 @@ def test_bulk_writer_against_the_references_own_ring(tag, game, n):
     eng.close()
 
 
+def test_bulk_writer_honours_the_references_augmentation_switches():
+    """utils/data_enhancer.py:29-45 under config/utils_config.py's switches: rotation + flip = the 8 rows (pinned above),
+    rotation only = the four rotations, flip only = the flipped sample ALONE, enhancement off = the sample itself.  The mode
+    comes from the switches the pool's own module holds (as its put_tupule_experience would read them); device tensors in."""
+    import sys
+    import types
+
+    from alphazero_amd import Engine
+    from alphazero_amd.samples import SharedRingWriter
+
+    c = _ring_cases()["gomoku9"]
+    eng = Engine(2, 4, 4, board_size=9, device="cuda:0")
+    d = eng.dims
+    st = torch.from_numpy(c["states"].astype(np.float32))[:5].cuda()
+    pi, z = torch.from_numpy(c["pis"])[:5].cuda(), torch.from_numpy(c["z"])[:5].cuda()
+    full = _RefLikeRing(64, (d.nn_channels, d.height, d.width), d.n_action, 2)
+    assert SharedRingWriter(full, eng).mode == "rot+flip" and SharedRingWriter(full, eng).put_batch(st, pi, z) == 40
+    mod = types.ModuleType("fake_share_ring_buffer")
+    sys.modules[mod.__name__] = mod
+    ring_cls = type("Ring", (_RefLikeRing,), {"__module__": mod.__name__})
+    try:
+        for flags, mode, rows in (((True, True, False), "rot", (0, 2, 4, 6)), ((True, False, True), "flip", (1,)),
+                                  ((False, True, True), "none", (0,)), ((True, False, False), "none", (0,))):
+            mod.USE_DATA_ENHANCEMENT, mod.USE_ROATATION, mod.USE_FLIP = flags
+            ring = ring_cls(64, (d.nn_channels, d.height, d.width), d.n_action, 2)
+            w = SharedRingWriter(ring, eng)
+            assert w.mode == mode
+            assert w.put_batch(st, pi, z) == 5 * len(rows)
+            sel = [8 * i + r for i in range(5) for r in rows]
+            k = len(sel)
+            assert ring._write_idx.value == k and ring._size.value == k and ring._total_written.value == k
+            assert torch.equal(ring._states[:k], full._states[sel]) and torch.equal(ring._prior[:k], full._prior[sel])
+            assert torch.equal(ring._values[:k], full._values[sel])
+    finally:
+        del sys.modules[mod.__name__]
+    eng.close()
+
+
 @pytest.mark.parametrize("kind", ["gomokunet-128x4-fused-bf16", "quicknet-128x2x3-fused-f32", "quicknet-128x2x3-fused-bf16",
                                   "quicknet-128x2x3-pytorch-f32"])
 def test_config5_shape_self_play_train_loop(kind):
