@@ -498,7 +498,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
             f32_equiv = tw_fl / (tw_ms * 1e-3) / 1e12
             if h2:
                 tw_fl *= H2_MFMA_PER_PRODUCT  # what the f16 pipe executes
-            ttraffic, tnote = pmc_traffic(tower_kernel)
+            ttraffic, tnote = pmc_traffic("k_tower_h1_f16" if dtype_name == "f16r" else tower_kernel)
             net_roofline = {"bound": "mfma", "kernel": tower_kernel, "achieved": tw_fl / (tw_ms * 1e-3) / 1e12, "peak": peak,
                         "unit": "TFLOP/s", "frac": tw_fl / (tw_ms * 1e-3) / 1e12 / peak, "traffic": ttraffic,
                         "traffic_note": tnote, "flops_per_launch": tw_fl, "boards_per_launch": evals_per_launch,
