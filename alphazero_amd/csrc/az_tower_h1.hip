@@ -67,7 +67,7 @@ constexpr int DUMP_BYTES = TPW * 16 * PITCH;  // where the pad lanes' epilogue s
 constexpr int RG_BYTES = ((RGW + 1) * 4 + 15) / 16 * 16;  // one board's packed input: RGW ring words + the player word
 // act | dump | two packed inputs (this board's, the next one's) | hand-over words | head filter fragments | residual selector fragments | per layer: 64 biases + 1 / SW + SW
 static size_t lds_bytes(int n_conv_layers) { return (size_t)ACT_BYTES + DUMP_BYTES + 2 * RG_BYTES + 16 + 4096 + (size_t)(n_conv_layers + 1) * (C + 4) * 4; }
-constexpr int MAX_LAYERS = 64;  // (LDS: two workgroups per CU up to here)
+constexpr int MAX_LAYERS = 64;  // (the bias table grows with depth: two workgroups fit a CU's 160 KiB up to 44 conv layers, one beyond)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 

@@ -180,7 +180,7 @@ def test_runner_search_graph_replay_matches_eager(oracle, kind):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("kind", ["gomokunet-f32", "quicknet-bf16", "dab-smallnet"])
+@pytest.mark.parametrize("kind", ["gomokunet-f32", "quicknet-bf16", "dab-smallnet", "gomokunet15-rowtile-bf16", "gomokunet15-rowtile-f16"])
 def test_graph_replay_after_weight_refresh_matches_eager(oracle, kind):
     """A weight publish between two moves: ``refresh()`` re-folds the module's new weights into the evaluator's packed tensors.
     A search graph captured BEFORE the refresh has those tensors' addresses baked in, so the refresh must rewrite them in place
@@ -192,9 +192,14 @@ def test_graph_replay_after_weight_refresh_matches_eager(oracle, kind):
 
     rng = np.random.default_rng(31)
     torch.manual_seed(8)
+    fused = True
     if kind == "dab-smallnet":
         game, n, G, sims, dt = 1, 3, 64, 40, torch.float32
         mk = lambda: DotsAndBoxesNet()
+    elif "rowtile" in kind:  # az_tower_h1.hip under graph replay: its one-board-ahead hand-over, scales and selector fragments
+        game, n, G, sims, dt = 2, 15, 40, 30, torch.float32
+        fused = "bf16r" if kind.endswith("bf16") else "f16"
+        mk = lambda: _randomised(GomokuNet(n, 64, 2))
     else:
         game, n, G, sims = 2, 9, 48, 40
         dt = torch.float32 if kind.endswith("f32") else torch.bfloat16
@@ -221,13 +226,13 @@ def test_graph_replay_after_weight_refresh_matches_eager(oracle, kind):
             e.reset_games(None)
 
     eng = fresh_engine()
-    run = SelfPlayRunner(eng, net, sims, fused=True, use_graph=True)
+    run = SelfPlayRunner(eng, net, sims, fused=fused, use_graph=True)
     _fix_noise(run, noise_np)
     run.search()  # captures the graph on the OLD weights
     old = _results(eng)
     g0, gen0 = run._graph, run.fused.generation
     assert g0 is not None
-    names = ("w1", "w2", "head", "w0", "wl", "bias", "headw", "wp", "w1p", "w2p")
+    names = ("w1", "w2", "head", "w0", "wl", "bias", "headw", "wp", "w1p", "w2p", "sw")
     ptrs = {k: getattr(run.fused, k).data_ptr() for k in names if isinstance(getattr(run.fused, k, None), torch.Tensor)}
     assert ptrs
     net.load_state_dict(new_weights)
@@ -240,7 +245,7 @@ def test_graph_replay_after_weight_refresh_matches_eager(oracle, kind):
     eng.close()
 
     eng = fresh_engine()
-    run2 = SelfPlayRunner(eng, net, sims, fused=True, use_graph=False)
+    run2 = SelfPlayRunner(eng, net, sims, fused=fused, use_graph=False)
     _fix_noise(run2, noise_np)
     run2.search()
     eager = _results(eng)
