@@ -1,6 +1,6 @@
 // az_tower_h1.hip -- the 15x15 / 64-channel GomokuModel-family conv tower on the 16-bit MFMA pipe with ROW TILES (gfx950).
 //
-// The throughput-mode tower (az_tower.hip, bf16, 32-cell tiles) spends 12 % of its MFMAs on the 31 padding cells of its eighth
+// The throughput-mode tower of az_tower.hip (bf16, 32-cell tiles) spends 12 % of its MFMAs on the 31 padding cells of its eighth
 // tile and 53 VALU instructions per 48 MFMAs on tap masks and swizzled fragment addresses.  This kernel removes both by
 // making a cell tile ONE BOARD ROW: 15 cells + one lane on a zero column.
 //   * LDS image: act[row -1 .. 15][col -1 .. 14][64 ch], rows of 16 cells -- the zero column at col -1 of row r is also col 15
@@ -12,15 +12,21 @@
 //     odd half has 7; the halves are swapped between the two workgroups of a CU so every SIMD carries 15) x channel tiles
 //     2 (w >> 1), + 1, whose rows the host orders so that a lane's 2 x 4 results are eight CONSECUTIVE channels (one 16-byte
 //     store per tile and layer).  Per k-step of 32 channels: 8 ds_read_b128 feed 16 v_mfma_f32_16x16x32; the weights
-//     [tap][k-step][co tile 4][lane][8] come straight from L2 into registers two k-steps ahead (no LDS traffic for A at all).
-//   * element type: bf16 (no scaling), or f16 with the scaling of az_tower_h2.hip (activations x 16, every layer's weights x a
-//     host-chosen power of two, both exact and undone on the f32 accumulators; an activation above 4,094 raises the flag):
-//     8x the precision of bf16 at the same MFMA rate.
-// Layers run in place (barrier, epilogue, barrier); a block's first epilogue reads the residual it overwrites and starts the
-// second conv's accumulators at bias + residual.  The 1x1 head convs are one more MFMA pair per tile; f32 feature rows as
-// az_tower_f32.hip writes them, so az_heads_forward_f32 finishes the evaluation.  Boards are handed out by the library's
-// ticket counter; input: the engine's packed leaf batch (+ flags) or dense f32 planes.  No counterpart in the reference beyond
-// the model contract (nn_models/base.py:17-19; network: examples/gomoku/model.py:41-90).
+//     [step][co tile 4][lane][8] come straight from L2 into registers two k-steps ahead (no LDS traffic for A at all).
+//   * the stem is THREE steps, one per kernel row: the input expansion writes a cell's k-step as [left neighbour's 9 planes |
+//     its own | right neighbour's] (k = 9 tx + plane, 27 of 32 used), so a row's three taps are one MFMA step.
+//   * everything outside the k loop that can be an MFMA is one (VALU instructions issue at a fraction of their rate beside the
+//     partner workgroup's MFMA stream): the block's residual add (a 0 / 1 selector A fragment routes the eight channels a
+//     lane reads back -- that tile's B fragment of k-step w >> 1 -- into its accumulator rows, C = the next layer's bias) and the
+//     three 1x1 head convs (the filters as rows 0 .. 2 of an A fragment, two MFMAs per tile).
+//   * boards come from the library's ticket counter ONE BOARD AHEAD: ticket, flag byte and packed input of the next board are
+//     fetched under the current board's layers; biases and scales sit in LDS.
+//   * element type: bf16 (no scaling; bf16 feature rows for az_heads_forward), or f16 with exact power-of-two scalings
+//     (activations x 16; a layer's weights x a power of two only when they are all tiny; undone on the f32 accumulators; an
+//     activation above 4,094 raises the flag; f32 feature rows for az_heads_forward_f32): 8x the precision of bf16 at the same
+//     MFMA rate.
+// Layers run in place (barrier, epilogue, barrier).  Input: the engine's packed leaf batch (+ flags) or dense f32 planes.
+// No counterpart in the reference beyond the model contract (nn_models/base.py:17-19; network: examples/gomoku/model.py:41-90).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
