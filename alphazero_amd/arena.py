@@ -38,11 +38,16 @@ def resolve_game(game_cls) -> tuple[int, int]:
             raise EngineError("only the 3x3-box dots-and-boxes board has a native rule kernel")
         return GAME_DAB, 3
     if "Gomoku" in name:
-        n = int(getattr(game_cls, "BOARD_SIZE", 15))
-        if n not in (9, 15) or int(getattr(game_cls, "WIN_LENGTH", 5)) != 5:
-            raise EngineError("gomoku rule kernels exist for 9x9 and 15x15, five in a row")
+        n, k = int(getattr(game_cls, "BOARD_SIZE", 15)), int(getattr(game_cls, "WIN_LENGTH", 5))
+        if not (3 <= n <= 15 and 3 <= k <= 6 and k <= n):
+            raise EngineError("gomoku rule kernels cover BOARD_SIZE 3 .. 15 with WIN_LENGTH 3 .. 6")
         return GAME_GOMOKU, n
     raise EngineError(f"no native rule kernel for game class {name}")
+
+
+def resolve_win_length(game_cls) -> int:
+    """the reference's WIN_LENGTH constant of a gomoku class (examples/gomoku/game.py:22); 5 for everything else (ignored)"""
+    return int(getattr(game_cls, "WIN_LENGTH", 5)) if "Gomoku" in getattr(game_cls, "__name__", "") or hasattr(game_cls, "WIN_LENGTH") else 5
 
 
 TaoSchedule = Union[float, Sequence[float], Callable[[int], float]]
@@ -281,6 +286,7 @@ class ChessArena:
         self.model.eval()
         self.game_cls = game_cls
         self.game_id, self.board_size = resolve_game(game_cls)
+        self.win_length = resolve_win_length(game_cls)
         self.num_simulation, self.c_puct, self.epsilon, self.alpha = num_simulation, c_puct, epsilon, alpha
         self.n_slots, self.nn_dtype = n_slots, nn_dtype
         self.fused, self.use_graph = fused, use_graph
@@ -292,7 +298,7 @@ class ChessArena:
         if slots not in self._engines:
             self._engines[slots] = Engine(self.game_id, slots, self.num_simulation, board_size=self.board_size,
                                           c_puct=self.c_puct, epsilon=self.epsilon, nn_dtype=self.nn_dtype,
-                                          device=self.device)
+                                          device=self.device, win_length=self.win_length)
         return self._engines[slots]
 
     # ---- reference surface -------------------------------------------------------------------

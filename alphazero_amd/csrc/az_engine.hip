@@ -74,6 +74,7 @@ enum : int { ERR_EDGE_CAP = 1, ERR_NODE_CAP = 2, ERR_DEPTH_CAP = 4, ERR_ILLEGAL 
 struct View {  // kernel argument: raw device pointers + sizes
   int G, E, D;
   int K;        // leaves per tree per step (1 = the reference's sequential search); per-simulation arrays hold G*K rows
+  int win;      // gomoku: stones in a row that win (WIN_LENGTH)
   float c_puct, epsilon;
   double vl;    // VIRTUAL_LOSS (config/basic.py:25), used by the wave kernels only
   int32_t *waveCnt;              // [G] leaves queued by the last k_select_wave
@@ -429,7 +430,7 @@ __device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input
         base = kid - 1; vt = (int)(w.meta & META_V); nParent = w.n;
         continue;
       }
-      const int term = uni(GT::terminal(cur, w.act, mover, ply + depth, lane));
+      const int term = uni(GT::terminal(cur, w.act, mover, ply + depth, lane, v.win));
       if (term != T_NONE) { kind = KIND_TERMINAL; tval = terminal_value(term, pl); }
       break;
     }
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(64) void k_select_wave(View v, OutT *nn_input, int 
           base = kid - 1; vt = (int)(w.meta & META_V); nParent = w.n;
           continue;
         }
-        const int term = uni(GT::terminal(cur, w.act, mover, ply + depth, lane));
+        const int term = uni(GT::terminal(cur, w.act, mover, ply + depth, lane, v.win));
         if (term != T_NONE) { kind = KIND_TERMINAL; tval = terminal_value(term, pl); }
         break;
       }
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(64) void k_play_moves(View v, const float *invTao, 
   for (int k = lane; k < A; k += 64) tv[k] = vis[k];
   const int np = GT::apply(cur, a, player, lane);
   if (lane < GT::SW) tb[(size_t)(ply + 1) * GT::SW + lane] = cur[lane];
-  const int term = uni(GT::terminal(cur, a, player, ply + 1, lane));
+  const int term = uni(GT::terminal(cur, a, player, ply + 1, lane, v.win));
   if (lane == 0) {
     v.trajPlayer[(size_t)g * (GT::PMAX + 1) + ply] = (int8_t)player;
     v.ply[g] = ply + 1;
@@ -1300,12 +1301,19 @@ struct DeviceGuard {
     switch ((e)->cfg.game) {                                                                \
       case AZ_GAME_TICTACTOE: { using GT = az::TicTacToe; BODY; } break;                    \
       case AZ_GAME_DAB: { using GT = az::Dab; BODY; } break;                                \
-      default:                                                                              \
-        if ((e)->cfg.board_size == 9) { using GT = az::Gomoku<9>; BODY; }                   \
-        else { using GT = az::Gomoku<15>; BODY; }                                           \
+      default:  /* gomoku N x N: examples/gomoku/game.py's BOARD_SIZE, any value 3 .. 15 */       \
+        switch ((e)->cfg.board_size) {                                                      \
+          AZ_GOMOKU_CASE(3, BODY) AZ_GOMOKU_CASE(4, BODY) AZ_GOMOKU_CASE(5, BODY)           \
+          AZ_GOMOKU_CASE(6, BODY) AZ_GOMOKU_CASE(7, BODY) AZ_GOMOKU_CASE(8, BODY)           \
+          AZ_GOMOKU_CASE(9, BODY) AZ_GOMOKU_CASE(10, BODY) AZ_GOMOKU_CASE(11, BODY)         \
+          AZ_GOMOKU_CASE(12, BODY) AZ_GOMOKU_CASE(13, BODY) AZ_GOMOKU_CASE(14, BODY)        \
+          default: { using GT = az::Gomoku<15>; BODY; } break;                              \
+        }                                                                                   \
         break;                                                                              \
     }                                                                                       \
   } while (0)
+// (variadic: by the time BODY arrives here its own macros are expanded and their commas stand at the top level)
+#define AZ_GOMOKU_CASE(NN, ...) case NN: { using GT = az::Gomoku<NN>; __VA_ARGS__; } break;
 
 template <class GT>
 static void fill_dims(az_dims &d) {
@@ -1330,8 +1338,9 @@ int az_create(const az_config *cfg, az_engine **out) {
   if (!cfg || !out) { g_create_err = "null argument"; return AZ_EINVAL; }
   *out = nullptr;
   if (cfg->game < AZ_GAME_TICTACTOE || cfg->game > AZ_GAME_GOMOKU) { g_create_err = "unknown game"; return AZ_EINVAL; }
-  if (cfg->game == AZ_GAME_GOMOKU && cfg->board_size != 9 && cfg->board_size != 15) {
-    g_create_err = "gomoku board_size must be 9 or 15"; return AZ_EINVAL;
+  const int win = cfg->win_length == 0 ? 5 : cfg->win_length;  // examples/gomoku/game.py:22
+  if (cfg->game == AZ_GAME_GOMOKU && (cfg->board_size < 3 || cfg->board_size > 15 || win < 3 || win > 6 || win > cfg->board_size)) {
+    g_create_err = "gomoku: board_size 3 .. 15, win_length 3 .. 6 (0 = 5) and <= board_size"; return AZ_EINVAL;
   }
   if (cfg->n_slots < 1 || cfg->max_sims < 1 || cfg->max_sims > 65535) {
     g_create_err = "n_slots >= 1 and 1 <= max_sims <= 65535 required"; return AZ_EINVAL;
@@ -1344,6 +1353,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   }
   az_engine *e = new az_engine();
   e->cfg = *cfg;
+  e->cfg.win_length = win;
   memset(&e->dims, 0, sizeof(e->dims));
   AZ_DISPATCH(e, fill_dims<GT>(e->dims));
   az_dims &d = e->dims;
@@ -1368,6 +1378,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   memset(&v, 0, sizeof(v));
   v.G = d.n_slots; v.E = d.edge_cap; v.D = d.depth_cap;
   v.K = cfg->leaves_per_step > 1 ? cfg->leaves_per_step : 1;
+  v.win = win;
   v.vl = 0.3;  // VIRTUAL_LOSS, config/basic.py:25 (az_set_virtual_loss)
   d.leaves_per_step = v.K;
   v.c_puct = cfg->c_puct; v.epsilon = cfg->epsilon;
@@ -1492,7 +1503,7 @@ int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32
   if (ply >= d.max_plies) { e->err = "position has no move left"; return AZ_EINVAL; }
   {  // a root that is already won is terminal: the reference evaluates it by rule (core/MCTS_alphazero.py:157-158), there is no search
     bool won = false;
-    AZ_DISPATCH(e, won = GT::host_won(words.data() + (size_t)7 * SW));
+    AZ_DISPATCH(e, won = GT::host_won(words.data() + (size_t)7 * SW, e->cfg.win_length));
     if (won) { e->err = "position is already terminal (a side has won)"; return AZ_EINVAL; }
   }
   // entries older than the start of the game must be the initial (empty) state

@@ -46,7 +46,7 @@ struct TicTacToe {
     return -player;
   }
   // after `mover` played `a`; nmoves = stones on the board
-  __device__ static int terminal(const uint32_t *s, int, int mover, int nmoves, int) {
+  __device__ static int terminal(const uint32_t *s, int, int mover, int nmoves, int, int /*win*/) {
     const uint32_t b = (mover == 1 ? s[0] : (s[0] >> 9)) & 0x1FFu;
     const uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
     bool win = false;
@@ -69,7 +69,7 @@ struct TicTacToe {
     return true;
   }
   // host: has either side already completed a line?  (az_set_position refuses such roots: the reference evaluates them by rule)
-  __host__ static bool host_won(const uint32_t *w) {
+  __host__ static bool host_won(const uint32_t *w, int /*win*/ = 0) {
     const uint32_t L[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x111u, 0x054u};
     for (int i = 0; i < 8; ++i)
       if ((w[0] & L[i]) == L[i] || ((w[0] >> 9) & L[i]) == L[i]) return true;
@@ -123,7 +123,7 @@ struct Dab {
     wave_sync();
     return done ? player : -player;
   }
-  __device__ static int terminal(const uint32_t *s, int, int, int, int) {
+  __device__ static int terminal(const uint32_t *s, int, int, int, int, int /*win*/) {
     if ((s[0] & 0xFFFFFFu) != 0xFFFFFFu) return T_NONE;
     const int p1 = __popc(s[1] & 0x1FFu), p2 = __popc((s[1] >> 9) & 0x1FFu);
     return p1 > p2 ? T_WIN_P1 : (p2 > p1 ? T_WIN_P2 : T_NO_WINNER);
@@ -153,7 +153,7 @@ struct Dab {
       }
     return true;
   }
-  __host__ static bool host_won(const uint32_t *) { return false; }  // terminal only when all 24 edges are drawn (ply == PMAX)
+  __host__ static bool host_won(const uint32_t *, int /*win*/ = 0) { return false; }  // terminal only when all 24 edges are drawn (ply == PMAX)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -173,16 +173,16 @@ struct Gomoku {
     wave_sync();
     return -player;
   }
-  // Only the mover can have made a five (the position before was not terminal), so the row-major
+  // Only the mover can have made a line (the position before was not terminal), so the row-major
   // scan of the reference (game.py:62-89) reduces to the four lines through the new stone.
-  // Lane l < 36 looks at direction l/9, offset l%9-4; any 5 consecutive set bits in a 9-window win
-  // (six or more in a row count, as in the reference).
-  __device__ static int terminal(const uint32_t *s, int a, int mover, int nmoves, int lane) {
+  // K = WIN_LENGTH (game.py:22; 3 .. 6, five by default).  Lane l < 4 (2K - 1) looks at direction l / (2K - 1), offset
+  // l % (2K - 1) - (K - 1); any K consecutive set bits in a (2K - 1)-window win (longer rows count, as in the reference).
+  __device__ static int terminal(const uint32_t *s, int a, int mover, int nmoves, int lane, int K) {
     const uint32_t *mine = s + (mover == 1 ? 0 : WC);
-    const int r = a / N, c = a % N;
+    const int r = a / N, c = a % N, span = 2 * K - 1;
     bool bit = false;
-    if (lane < 36) {
-      const int d = lane / 9, k = lane % 9 - 4;
+    if (lane < 4 * span) {
+      const int d = lane / span, k = lane % span - (K - 1);
       const int dr = (d == 0) ? 0 : 1, dc = (d == 0) ? 1 : (d == 1 ? 0 : (d == 2 ? 1 : -1));
       const int rr = r + k * dr, cc = c + k * dc;
       if (rr >= 0 && rr < N && cc >= 0 && cc < N) bit = bit_at(mine, rr * N + cc) != 0u;
@@ -191,9 +191,10 @@ struct Gomoku {
     bool win = false;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      uint32_t w = (uint32_t)(m >> (9 * d)) & 0x1FFu;
-      w = w & (w >> 1) & (w >> 2) & (w >> 3) & (w >> 4);
-      win |= (w != 0u);
+      uint32_t w = (uint32_t)(m >> (span * d)) & ((1u << span) - 1u);
+      uint32_t run = w;
+      for (int i = 1; i < K; ++i) run &= w >> i;  // bit j of run: stones j .. j + K - 1 of the window are all set
+      win |= (run != 0u);
     }
     if (win) return mover == 1 ? T_WIN_P1 : T_WIN_P2;
     return nmoves == A ? T_NO_WINNER : T_NONE;
@@ -211,7 +212,7 @@ struct Gomoku {
     }
     return true;
   }
-  __host__ static bool host_won(const uint32_t *w) {  // five (or more) in a row of either colour: game.py:62-89
+  __host__ static bool host_won(const uint32_t *w, int K = 5) {  // K (or more) in a row of either colour: game.py:62-89
     const int DR[4] = {0, 1, 1, 1}, DC[4] = {1, 0, 1, -1};
     for (int side = 0; side < 2; ++side) {
       const uint32_t *b = w + side * WC;
@@ -219,13 +220,13 @@ struct Gomoku {
         for (int c = 0; c < N; ++c)
           for (int d = 0; d < 4; ++d) {
             int k = 0;
-            for (; k < 5; ++k) {
+            for (; k < K; ++k) {
               const int rr = r + k * DR[d], cc = c + k * DC[d];
               if (rr < 0 || rr >= N || cc < 0 || cc >= N) break;
               const int i = rr * N + cc;
               if (!((b[i >> 5] >> (i & 31)) & 1u)) break;
             }
-            if (k == 5) return true;
+            if (k == K) return true;
           }
     }
     return false;

@@ -141,6 +141,19 @@ class Gomoku9Game(GomokuGame):
     AZ_GAME = (GAME_GOMOKU, 9)
 
 
+def gomoku_game(board_size: int, win_length: int = 5):
+    """GomokuGame with the reference's two constants set (examples/gomoku/game.py:21-22 BOARD_SIZE, WIN_LENGTH): any board
+    3 .. 15 with 3 .. 6 in a row to win has a native rule kernel (az::Gomoku<N> with the win length as a run-time value)."""
+    n, k = int(board_size), int(win_length)
+    if not (3 <= n <= 15 and 3 <= k <= 6 and k <= n):
+        raise ValueError("gomoku_game: board_size 3 .. 15, win_length 3 .. 6 and <= board_size")
+    if (n, k) == (15, 5):
+        return GomokuGame
+    if (n, k) == (9, 5):
+        return Gomoku9Game
+    return type(f"Gomoku{n}x{n}k{k}Game", (GomokuGame,), {"BOARD_SIZE": n, "N": n, "WIN_LENGTH": k, "AZ_GAME": (GAME_GOMOKU, n)})
+
+
 class DotsAndBoxesGame(BaseGame):
     """examples/dots_and_boxes/game.py: 3x3 boxes; state (3,4,4) = horizontal edges, vertical edges,
     box owners; action a<12: horizontal edge (a//3, a%3), else vertical edge ((a-12)//4, (a-12)%4);

@@ -14,7 +14,7 @@ from typing import Optional
 
 import torch
 
-from .arena import C_PUCT, EPSILON, TRAIN_NUM_SIMULATION, resolve_game
+from .arena import C_PUCT, EPSILON, TRAIN_NUM_SIMULATION, resolve_game, resolve_win_length
 from .engine import Engine, EngineError
 
 
@@ -31,7 +31,8 @@ def play_match(game_cls, model_a: torch.nn.Module, model_b: torch.nn.Module, n_g
         raise EngineError("play_match needs a GPU (no CPU fallback)")
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     game_id, board = resolve_game(game_cls)
-    eng = Engine(game_id, n_games, num_simulation, board_size=board, c_puct=c_puct, epsilon=EPSILON, device=dev)
+    eng = Engine(game_id, n_games, num_simulation, board_size=board, c_puct=c_puct, epsilon=EPSILON, device=dev,
+                 win_length=resolve_win_length(game_cls))
     d = eng.dims
     A = d.n_action
     models = (model_a.to(dev).eval(), model_b.to(dev).eval())

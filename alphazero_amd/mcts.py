@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from .arena import ALPHA, C_PUCT, EPSILON, TRAIN_NUM_SIMULATION, resolve_game
+from .arena import ALPHA, C_PUCT, EPSILON, TRAIN_NUM_SIMULATION, resolve_game, resolve_win_length
 from .engine import Engine, EngineError
 
 
@@ -20,6 +20,7 @@ class MCTS:
     def __init__(self, game_cls, device: Optional[torch.device] = None) -> None:
         self.game_cls = game_cls
         self.game_id, self.board_size = resolve_game(game_cls)
+        self.win_length = resolve_win_length(game_cls)
         self.device = torch.device(device) if device is not None else None
         self._engines: dict = {}
 
@@ -27,7 +28,7 @@ class MCTS:
         key = (num_simulation, float(c_puct), str(device))
         if key not in self._engines:
             self._engines[key] = Engine(self.game_id, 1, num_simulation, board_size=self.board_size, c_puct=c_puct,
-                                        epsilon=EPSILON, device=device)
+                                        epsilon=EPSILON, device=device, win_length=self.win_length)
         return self._engines[key]
 
     def search(self, model: torch.nn.Module, root_state: torch.Tensor, root_player: int,

@@ -43,7 +43,7 @@ typedef struct az_engine az_engine;
 
 typedef struct az_config {
   int32_t game;        /* AZ_GAME_* */
-  int32_t board_size;  /* gomoku N; ignored otherwise */
+  int32_t board_size;  /* gomoku N = examples/gomoku/game.py:21 BOARD_SIZE, 3 .. 15; ignored otherwise */
   int32_t n_slots;     /* concurrent games (one tree each) */
   int32_t max_sims;    /* simulations per move the trees are sized for (TRAIN_NUM_SIMULATION) */
   float c_puct;        /* config/basic.py:12 */
@@ -54,6 +54,8 @@ typedef struct az_config {
   int32_t leaves_per_step; /* 0 or 1: the reference's sequential search (one leaf per tree per step); 2 .. 16: virtual loss /
                               in-tree leaf batching (INFER_BATCH_SIZE, config/basic.py:28) through az_select_wave /
                               az_expand_wave -- the per-simulation batch then has n_slots * leaves_per_step rows */
+  int32_t win_length;  /* gomoku: stones in a row that win = examples/gomoku/game.py:22 WIN_LENGTH, 3 .. 6 and <= board_size;
+                          0 = the reference's 5; ignored otherwise */
 } az_config;
 
 typedef struct az_dims {

@@ -54,6 +54,24 @@ def _p(a, ty):
     return None if a is None else a.ctypes.data_as(ty)
 
 
+class win_length:
+    """``with win_length(k):`` the oracle's rule code runs with the reference's WIN_LENGTH constant (examples/gomoku/game.py:22)
+    set to k (3 .. 6) -- process-wide, restored on exit.  Test infrastructure, like everything here."""
+
+    def __init__(self, k: int):
+        self.k, self.old = int(k), None
+
+    def __enter__(self):
+        if not 3 <= self.k <= 6:
+            raise ValueError("WIN_LENGTH 3 .. 6")
+        self.old = lib().az_oracle_set_win_length(self.k)
+        return self
+
+    def __exit__(self, *exc):
+        lib().az_oracle_set_win_length(self.old)
+        return False
+
+
 def dims(game: int, board_size: int = 15) -> dict:
     out = (C.c_int * 6)()
     if lib().az_oracle_dims(game, board_size, out) != 0:

@@ -1,4 +1,5 @@
 import os
+import re
 import sys
 
 import pytest
@@ -40,8 +41,17 @@ def game_of(tag):
         return 0, 3
     if tag.startswith("dab"):
         return 1, 3
-    if tag.startswith("gomoku15"):
-        return 2, 15
-    if tag.startswith("gomoku9"):
-        return 2, 9
+    m = re.match(r"gomoku(\d+)", tag)
+    if m:
+        return 2, int(m.group(1))
     raise KeyError(tag)
+
+
+def win_of(tag):
+    """fixture tag -> the reference's WIN_LENGTH the fixture was recorded under ("gomoku7k4_1" -> 4; 5 where the tag does not say)"""
+    m = re.match(r"gomoku\d+k(\d)", tag)
+    return int(m.group(1)) if m else 5
+
+
+# gomoku under other values of the reference's BOARD_SIZE / WIN_LENGTH constants (tests/golden/make_golden.py mnk)
+MNK_RULES = [(f"gomoku{n}k{k}", 2, n) for n, k in ((7, 4), (11, 5), (6, 3), (13, 6), (5, 5), (3, 3), (12, 4), (8, 6))]

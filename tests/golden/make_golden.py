@@ -664,6 +664,79 @@ def make_ring():
     np.savez_compressed(os.path.join(OUT, "ring.npz"), **out)
 
 
+# ------------------------------------------------------------ gomoku under other BOARD_SIZE / WIN_LENGTH constants ----
+MNK = [(7, 4), (11, 5), (6, 3), (13, 6), (5, 5), (3, 3), (12, 4), (8, 6)]  # (BOARD_SIZE, WIN_LENGTH): examples/gomoku/game.py:21-22
+
+
+def gomoku_scripts_nk(n, k):
+    def rc(r, c):
+        return r * n + c
+
+    S = []
+    if n >= k + 1:  # (a second row / column for the other player)
+        S.append([x for i in range(k) for x in (rc(0, i), rc(n - 1, i))][:2 * k - 1])                    # horizontal, P1
+        S.append([x for i in range(k) for x in (rc(i, n - 1), rc(i, 0))][:2 * k - 1])                    # vertical on the last column
+        S.append([x for i in range(k) for x in (rc(n - k + i, n - k + i), rc(0, i))][:2 * k - 1])        # diagonal into the corner
+        S.append([x for i in range(k) for x in (rc(i, k - 1 - i), rc(n - 1, i))][:2 * k - 1])            # anti-diagonal from the left edge
+    if n >= 2 * k + 1:
+        # k + 1 in a row, the gap filled last; P2 scattered on two rows with gaps
+        cols = [c for c in range(k + 1) if c != k // 2] + [k // 2]
+        p1 = [rc(2, c) for c in cols]
+        p2 = [rc(n - 1 - (i % 2), 2 * i) for i in range(k)]
+        S.append([x for i in range(k + 1) for x in ((p1[i], p2[i]) if i < k else (p1[i],))])
+        # the second player wins with a vertical line; P1 scattered
+        S.append([x for i in range(k) for x in (rc(n - 1 - (i % 2), 2 * i), rc(i, 3))])
+    return S
+
+
+class GomokuNModel(BaseModel):
+    """a small net of the reference's model contract for an n x n board (the reference's GomokuModel hard-codes 15)"""
+
+    def __init__(self, n):
+        super().__init__()
+        self._s = torch.nn.Sequential(torch.nn.Conv2d(9, 8, 3, padding=1), torch.nn.ReLU())
+        self._p = torch.nn.Sequential(torch.nn.Flatten(1), torch.nn.Linear(8 * n * n, n * n))
+        self._v = torch.nn.Sequential(torch.nn.Flatten(1), torch.nn.Linear(8 * n * n, 1), torch.nn.Tanh())
+
+    @property
+    def shared_layers(self):
+        return self._s
+
+    def policy_head(self, x):
+        return self._p(x)
+
+    def value_head(self, x):
+        return self._v(x)
+
+
+def make_mnk():
+    """the reference's own GomokuGame / MCTS with its two constants changed: rule games (scripted + random) for every pair of
+    MNK, and searches on three of them"""
+    try:
+        for n, k in MNK:
+            GomokuGame.BOARD_SIZE, GomokuGame.WIN_LENGTH = n, k
+            rules_fixture(f"gomoku{n}k{k}", GomokuGame, gomoku_scripts_nk(n, k), 14, 900 + 16 * n + k)
+        rng = np.random.default_rng(11)
+        cases = []
+        for j, (n, k, specs) in enumerate([(7, 4, [(0, 80, True), (8, 120, True), (20, 60, False)]),
+                                           (11, 5, [(0, 60, True), (30, 90, True)]),
+                                           (6, 3, [(2, 100, True), (5, 150, False)])]):
+            GomokuGame.BOARD_SIZE, GomokuGame.WIN_LENGTH = n, k
+            torch.manual_seed(700 + j)
+            model = GomokuNModel(n).eval()
+            for i, (nm, ns, ud) in enumerate(specs):
+                c = search_case(GomokuGame, model, nm, ns, ud, rng, 800 + 10 * j + i)
+                cases.append((f"gomoku{n}k{k}_{i}", c))
+                print("search", cases[-1][0], "moves", nm, "sims", ns, "maxdepth", c["trace"][:, 0].max())
+        out = {"tags": np.array([t for t, _ in cases])}
+        for t, c in cases:
+            for kk, v in c.items():
+                out[f"{t}__{kk}"] = v
+        np.savez_compressed(os.path.join(OUT, "search_mnk.npz"), **out)
+    finally:
+        GomokuGame.BOARD_SIZE, GomokuGame.WIN_LENGTH = 15, 5
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rules", "search", "selfplay", "augment", "loss", "quick"]
     if "quick" in which:
@@ -682,3 +755,5 @@ if __name__ == "__main__":
         make_draw()
     if "ring" in which:
         make_ring()
+    if "mnk" in which:  # gomoku under other BOARD_SIZE / WIN_LENGTH constants
+        make_mnk()

@@ -33,5 +33,7 @@ def test_create_rejects_bad_config_without_gpu():
     bad = AzConfig(7, 15, 4, 10, 1.0, 0.25, 0, 0, 0, 0)
     assert lib.az_create(ctypes.byref(bad), ctypes.byref(h)) == -1
     assert b"unknown game" in lib.az_last_error(None)
-    bad = AzConfig(2, 13, 4, 10, 1.0, 0.25, 0, 0, 0, 0)
-    assert lib.az_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    for board, win in ((16, 5), (2, 0), (13, 7), (4, 5), (9, 2)):  # gomoku: BOARD_SIZE 3 .. 15, WIN_LENGTH 3 .. 6 and <= the board
+        bad = AzConfig(2, board, 4, 10, 1.0, 0.25, 0, 0, 0, 0, win)
+        assert lib.az_create(ctypes.byref(bad), ctypes.byref(h)) == -1, (board, win)
+        assert b"board_size 3 .. 15" in lib.az_last_error(None)

@@ -58,6 +58,49 @@ def test_arena_self_play_replays_like_the_reference(oracle, name, game, n, A, si
         assert float(z[0]) == float(r["z"][t])
 
 
+@pytest.mark.parametrize("n,k", [(7, 4), (12, 4), (6, 3)])
+def test_arena_on_a_gomoku_class_with_other_constants(oracle, n, k):
+    """the drop-in contract for the reference's GomokuGame with its BOARD_SIZE / WIN_LENGTH constants edited
+    (examples/gomoku/game.py:21-22): ChessArena maps the class to az::Gomoku<N> with the win length as a run-time value; a
+    seeded game replays on the oracle running the same constants, and the mirror's own static rules agree with the result"""
+    from alphazero_amd import games
+    from alphazero_amd.arena import ChessArena
+    from alphazero_amd.mcts import MCTS
+
+    cls = games.gomoku_game(n, k)
+    assert cls.BOARD_SIZE == n and cls.WIN_LENGTH == k
+    A, sims, seed = n * n, 30, 77
+    noise, expo = _reference_draws(seed, A, A)
+    arena = ChessArena(functools.partial(HashNet, A, 5.0), cls, torch.device("cuda:0"), num_simulation=sims)
+    assert (arena.board_size, arena.win_length) == (n, k)
+    pool = ListPool()
+    torch.manual_seed(seed)
+    arena.self_play(1.0, pool)
+    with oracle.win_length(k):
+        d = oracle.dims(2, n)
+        ev = oracle.torch_eval(HashNet(A, 5.0), (d["cin"], d["H"], d["W"]))
+        r = oracle.self_play(2, n, sims, 1.0, expo, ev, noise=noise, max_plies=A)
+    assert len(pool.items) == r["plies"]
+    for j, (st, pi, z) in enumerate(pool.items):
+        t = r["plies"] - 1 - j
+        assert st.shape == (1, 9, n, n) and np.array_equal(st.numpy().reshape(-1), r["nn_states"][t])
+        assert np.array_equal(pi.numpy().reshape(-1), r["pis"][t]) and float(z[0]) == float(r["z"][t])
+    # the final board through the mirror's own rules (games.GomokuGame._get_winner is generic in both constants)
+    last_state = pool.items[0][0][0, 7].clone()
+    a_last = int(r["actions"][-1])
+    mover = 1 if (r["plies"] - 1) % 2 == 0 else -1
+    final, _ = cls.next_state(last_state, a_last, mover)
+    assert cls.is_terminal(final)
+    w = cls._get_winner(final)
+    assert (w is None) == (r["result"] == 0.0) and (w is None or w == mover)
+    # and the single-position adapter
+    g = cls()
+    g.step(n + 1)
+    pi = MCTS(cls).search(HashNet(A, 5.0).cuda(), g.get_state(), g.get_player(), history_state=g.get_history(), num_simulation=20,
+                          use_Dirichlet=False)
+    assert pi.shape == (1, A) and abs(float(pi.sum()) - 1.0) < 1e-5 and float(pi[0, n + 1]) == 0.0
+
+
 @pytest.mark.parametrize("name,game,n,A,sims", GAMES)
 def test_mcts_search_adapter(oracle, name, game, n, A, sims):
     from alphazero_amd.mcts import MCTS

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from .conftest import game_of, load_cases
+from .conftest import game_of, load_cases, win_of
 
 pytestmark = pytest.mark.gpu
 
@@ -101,6 +101,43 @@ class _LineNet(torch.nn.Module):
         return logits, value.view(B, 1)
 
 
+@pytest.mark.parametrize("n,k,sims", [(7, 4, 150), (11, 5, 100), (6, 3, 200), (13, 6, 80), (5, 5, 120), (4, 3, 150), (10, 4, 100), (14, 5, 60)])
+def test_other_board_sizes_and_win_lengths_match_oracle(oracle, n, k, sims):
+    """gomoku with the reference's BOARD_SIZE / WIN_LENGTH constants at other values (examples/gomoku/game.py:21-22): searches from
+    random mid-game positions (short win lengths: many terminal leaves inside the tree) and whole self-play games == the oracle
+    running the same rule code with the same constants"""
+    rng = np.random.default_rng(4000 + 16 * n + k)
+    G = 16
+    with oracle.win_length(k):
+        d = oracle.dims(2, n)
+        A = d["A"]
+        eng = _engine(2, n, G, sims, win_length=k)
+        assert eng.dims.n_action == A
+        pos = [_random_position(oracle, 2, n, int(rng.integers(0, min(A // 2, 2 * k + 6))), rng) for _ in range(G)]
+        for g, (h, p) in enumerate(pos):
+            eng.set_position(g, h, p)
+        noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
+        scale = 6.0
+        pi, visits, q, prior = _run_search(eng, sims, lambda x, l, v: eng.eval_hash(x, l, v, scale), torch.from_numpy(noise_np).cuda())
+        fn, ctx, _keep = oracle.hash_eval(scale)
+        for g, (h, p) in enumerate(pos):
+            r = oracle.search(2, n, h[-1], p, h, sims, fn, ctx, noise=noise_np[g])
+            assert np.array_equal(visits[g], r["visits"]) and np.array_equal(pi[g], r["pi"]), (n, k, g)
+            assert np.array_equal(q[g], r["child_q"]) and np.array_equal(prior[g], r["root_prior"]), (n, k, g)
+        assert eng.read_stats()["terminals"] > 0 or k > 3  # (three in a row: wins lie inside a 100-simulation tree)
+        # whole games
+        eng = _engine(2, n, 6, 24, win_length=k)
+        noise_tab = rng.dirichlet([0.3] * A, size=(6, A)).astype(np.float32)
+        expo_tab = rng.exponential(1.0, size=(6, A, A)).astype(np.float32)
+        acts, plies = _self_play(eng, 24, lambda x, l, v: eng.eval_hash(x, l, v, 5.0), noise_tab, expo_tab, 1.0)
+        _, _, _, result = eng.game_info()
+        result = result.cpu().numpy()
+        fn, ctx, _keep = oracle.hash_eval(5.0)
+        for g in sorted(plies):
+            r = oracle.self_play(2, n, 24, 1.0, expo_tab[g], fn, ctx, noise=noise_tab[g], max_plies=A)
+            assert r["plies"] == plies[g] and list(r["actions"]) == acts[g] and result[g] == r["result"], (n, k, g)
+
+
 @pytest.mark.parametrize("name,game,n,sims,moves", [("gomoku15", 2, 15, 220, 0), ("gomoku15", 2, 15, 150, 40), ("gomoku9", 2, 9, 120, 3)])
 def test_deep_narrow_trees_match_oracle(oracle, name, game, n, sims, moves):
     """One-line searches: paths far longer than a wavefront is wide (the backup's second loop), a terminal leaf at the
@@ -155,16 +192,17 @@ def test_all_legal_priors_underflow_is_an_error_like_the_reference():
         eng.check()
 
 
-SEARCH = load_cases("search.npz")
+SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SEARCH))
 def test_search_matches_reference_golden(oracle, tag):
-    """The reference's own recorded searches; the network is replayed from the recorded table."""
+    """The reference's own recorded searches; the network is replayed from the recorded table.  (gomoku<N>k<K>: recorded with
+    the reference's BOARD_SIZE / WIN_LENGTH constants set to N / K.)"""
     c = SEARCH[tag]
     game, n = game_of(tag)
     sims = int(c["num_sim"])
-    eng = _engine(game, n, 1, sims)
+    eng = _engine(game, n, 1, sims, win_length=win_of(tag))
     d = eng.dims
     eng.set_position(0, c["history"].astype(np.float32), int(c["root_player"]))
     table = {c["eval_in"][i].astype(np.float32).tobytes(): (c["eval_logits"][i], c["eval_value"][i])

@@ -10,15 +10,21 @@ import os
 import numpy as np
 import pytest
 
-from .conftest import GOLDEN, game_of, load_cases
+from .conftest import GOLDEN, MNK_RULES, game_of, load_cases, win_of
 
 # gomoku9_draw: a scripted 81-ply game that fills the board with no five for either side (the reference says terminal, no
 # winner, evaluation 0: examples/gomoku/game.py:47-52) -- the case random playouts never reach
 RULES = [("tictactoe", 0, 3), ("dab", 1, 3), ("gomoku15", 2, 15), ("gomoku9", 2, 9), ("gomoku9_draw", 2, 9)]
 
 
-@pytest.mark.parametrize("name,game,n", RULES)
+@pytest.mark.parametrize("name,game,n", RULES + MNK_RULES)
 def test_rules_kat(oracle, name, game, n):
+    """(the gomoku<N>k<K> fixtures: the reference's GomokuGame with its BOARD_SIZE / WIN_LENGTH constants set to N / K)"""
+    with oracle.win_length(win_of(name)):
+        _rules_kat(oracle, name, game, n)
+
+
+def _rules_kat(oracle, name, game, n):
     z = np.load(os.path.join(GOLDEN, f"rules_{name}.npz"))
     d = oracle.dims(game, n)
     for g in range(int(z["n_games"])):
@@ -53,7 +59,7 @@ def _table(c):
             for i in range(len(c["eval_in"]))}
 
 
-SEARCH = load_cases("search.npz")
+SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SEARCH))
@@ -63,8 +69,9 @@ def test_search_kat(oracle, tag):
     ev = oracle.table_eval(_table(c))  # KeyError here <=> the oracle built a different NN input
     noise = c["noise"] if c["noise"].size else None
     D = c["trace"].shape[1]
-    r = oracle.search(game, n, c["root_state"].astype(np.float32), int(c["root_player"]),
-                      c["history"].astype(np.float32), int(c["num_sim"]), ev, noise=noise, trace_stride=D)
+    with oracle.win_length(win_of(tag)):
+        r = oracle.search(game, n, c["root_state"].astype(np.float32), int(c["root_player"]),
+                          c["history"].astype(np.float32), int(c["num_sim"]), ev, noise=noise, trace_stride=D)
     assert np.array_equal(r["visits"], c["visits"])           # bit-exact decisions
     assert np.array_equal(r["trace"], c["trace"])             # every simulation took the same path
     assert np.array_equal(r["pi"], c["pi"])                   # visits/sum: exact
@@ -82,9 +89,10 @@ def test_search_kat_reference_priors(oracle, tag):
     game, n = game_of(tag)
     ev = oracle.table_eval(_table(c))
     noise = c["noise"] if c["noise"].size else None
-    r = oracle.search(game, n, c["root_state"].astype(np.float32), int(c["root_player"]),
-                      c["history"].astype(np.float32), int(c["num_sim"]), ev, noise=noise,
-                      prior_override=c["priors"], trace_stride=c["trace"].shape[1])
+    with oracle.win_length(win_of(tag)):
+        r = oracle.search(game, n, c["root_state"].astype(np.float32), int(c["root_player"]),
+                          c["history"].astype(np.float32), int(c["num_sim"]), ev, noise=noise,
+                          prior_override=c["priors"], trace_stride=c["trace"].shape[1])
     assert np.array_equal(r["visits"], c["visits"])
     assert np.array_equal(r["trace"], c["trace"])
     assert np.array_equal(r["child_q"], c["child_q"])
