@@ -177,9 +177,11 @@ struct Gomoku {
   // scan of the reference (game.py:62-89) reduces to the four lines through the new stone.
   // K = WIN_LENGTH (game.py:22; 3 .. 6, five by default).  Lane l < 4 (2K - 1) looks at direction l / (2K - 1), offset
   // l % (2K - 1) - (K - 1); any K consecutive set bits in a (2K - 1)-window win (longer rows count, as in the reference).
-  __device__ static int terminal(const uint32_t *s, int a, int mover, int nmoves, int lane, int K) {
+  template <int K>
+  __device__ static int terminal_k(const uint32_t *s, int a, int mover, int nmoves, int lane) {
+    constexpr int span = 2 * K - 1;
     const uint32_t *mine = s + (mover == 1 ? 0 : WC);
-    const int r = a / N, c = a % N, span = 2 * K - 1;
+    const int r = a / N, c = a % N;
     bool bit = false;
     if (lane < 4 * span) {
       const int d = lane / span, k = lane % span - (K - 1);
@@ -191,13 +193,24 @@ struct Gomoku {
     bool win = false;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      uint32_t w = (uint32_t)(m >> (span * d)) & ((1u << span) - 1u);
+      const uint32_t w = (uint32_t)(m >> (span * d)) & ((1u << span) - 1u);
       uint32_t run = w;
+#pragma unroll
       for (int i = 1; i < K; ++i) run &= w >> i;  // bit j of run: stones j .. j + K - 1 of the window are all set
       win |= (run != 0u);
     }
     if (win) return mover == 1 ? T_WIN_P1 : T_WIN_P2;
     return nmoves == A ? T_NO_WINNER : T_NONE;
+  }
+  // (K is wave-uniform; each value gets the code of a compile-time constant -- as a run-time loop the check cost the tree
+  // kernel 3 of its 36 us)
+  __device__ static int terminal(const uint32_t *s, int a, int mover, int nmoves, int lane, int K) {
+    switch (K) {
+      case 3: return terminal_k<3>(s, a, mover, nmoves, lane);
+      case 4: return terminal_k<4>(s, a, mover, nmoves, lane);
+      case 6: return terminal_k<6>(s, a, mover, nmoves, lane);
+      default: return terminal_k<5>(s, a, mover, nmoves, lane);
+    }
   }
   __device__ static float plane(const uint32_t *s, int, int cell) {
     return (float)(int)bit_at(s, cell) - (float)(int)bit_at(s + WC, cell);
