@@ -34,9 +34,10 @@ def resolve_game(game_cls) -> tuple[int, int]:
     if "TicTacToe" in name:
         return GAME_TICTACTOE, 3
     if "DotsAndBoxes" in name:
-        if (getattr(game_cls, "BOX_ROWS", 3), getattr(game_cls, "BOX_COLS", 3)) != (3, 3):
-            raise EngineError("only the 3x3-box dots-and-boxes board has a native rule kernel")
-        return GAME_DAB, 3
+        r, c = int(getattr(game_cls, "BOX_ROWS", 3)), int(getattr(game_cls, "BOX_COLS", 3))
+        if not (2 <= r <= 5 and 2 <= c <= 5):
+            raise EngineError("dots-and-boxes rule kernels cover BOX_ROWS and BOX_COLS 2 .. 5")
+        return GAME_DAB, r
     if "Gomoku" in name:
         n, k = int(getattr(game_cls, "BOARD_SIZE", 15)), int(getattr(game_cls, "WIN_LENGTH", 5))
         if not (3 <= n <= 15 and 3 <= k <= 6 and k <= n):
@@ -48,6 +49,17 @@ def resolve_game(game_cls) -> tuple[int, int]:
 def resolve_win_length(game_cls) -> int:
     """the reference's WIN_LENGTH constant of a gomoku class (examples/gomoku/game.py:22); 5 for everything else (ignored)"""
     return int(getattr(game_cls, "WIN_LENGTH", 5)) if "Gomoku" in getattr(game_cls, "__name__", "") or hasattr(game_cls, "WIN_LENGTH") else 5
+
+
+def resolve_board_cols(game_cls) -> int:
+    """the reference's BOX_COLS constant of a dots-and-boxes class (examples/dots_and_boxes/game.py:25); 0 for everything else
+    (the engine's board_cols: ignored)"""
+    return int(getattr(game_cls, "BOX_COLS", 0)) if hasattr(game_cls, "BOX_ROWS") else 0
+
+
+def engine_constants(game_cls) -> dict:
+    """keyword arguments of ``Engine`` that carry a game class's constants beyond (game id, board size)"""
+    return {"win_length": resolve_win_length(game_cls), "board_cols": resolve_board_cols(game_cls)}
 
 
 TaoSchedule = Union[float, Sequence[float], Callable[[int], float]]
@@ -118,7 +130,7 @@ class SelfPlayRunner:
                     raise EngineError("the fused evaluator's board does not match the engine's game")
             else:  # the reference's tic-tac-toe / dots-and-boxes networks: one f32 kernel per evaluation
                 self.fused = SmallNetEvaluator(model)
-                if self.fused.game != engine.game:
+                if self.fused.game != engine.game or self.fused.n_action != engine.dims.n_action:
                     raise EngineError("the fused evaluator's network does not match the engine's game")
             ring, leaf, _, _, flags = engine.leaf_buffers()
             self._packed = (ring, leaf, None, None, flags)  # flag mode: the tower skips terminal leaves by itself
@@ -286,7 +298,7 @@ class ChessArena:
         self.model.eval()
         self.game_cls = game_cls
         self.game_id, self.board_size = resolve_game(game_cls)
-        self.win_length = resolve_win_length(game_cls)
+        self.win_length, self.board_cols = resolve_win_length(game_cls), resolve_board_cols(game_cls)
         self.num_simulation, self.c_puct, self.epsilon, self.alpha = num_simulation, c_puct, epsilon, alpha
         self.n_slots, self.nn_dtype = n_slots, nn_dtype
         self.fused, self.use_graph = fused, use_graph
@@ -298,7 +310,7 @@ class ChessArena:
         if slots not in self._engines:
             self._engines[slots] = Engine(self.game_id, slots, self.num_simulation, board_size=self.board_size,
                                           c_puct=self.c_puct, epsilon=self.epsilon, nn_dtype=self.nn_dtype,
-                                          device=self.device, win_length=self.win_length)
+                                          device=self.device, win_length=self.win_length, board_cols=self.board_cols)
         return self._engines[slots]
 
     # ---- reference surface -------------------------------------------------------------------

@@ -1034,8 +1034,8 @@ __global__ __launch_bounds__(64) void k_emit_samples(View v, const int32_t *slot
 // "flip" is a transpose).  Gather form: output variant t = 2k + flip of sample i goes to row
 // (write_idx + 8 i + t) mod capacity, i.e. straight into ring-buffer layout (utils/share_ring_buffer.py:39-46).
 struct AugTables {
-  uint8_t invEdge[8][24];  // dots-and-boxes: source action of destination action, per variant
-  uint8_t invBox[8][9];
+  uint8_t invEdge[8][60];  // dots-and-boxes (square boards up to 5 x 5 boxes): source action of destination action, per variant
+  uint8_t invBox[8][25];
 };
 
 template <class GT>
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(64) void k_augment(AugTables tb, const float *in_s,
   if (cap > 0) row %= cap;
   const float *is = in_s + (size_t)i * NIN, *ip = in_p + (size_t)i * A;
   float *os = out_s + (size_t)row * NIN, *op = out_p + (size_t)row * A;
-  if (GT::CS == 1) {
+  if constexpr (GT::CS == 1) {
     auto src = [&](int cell) {
       const int oi = cell / N, oj = cell % N, jj = flip ? N - 1 - oj : oj;
       const int si = k == 0 ? oi : (k == 1 ? jj : (k == 2 ? N - 1 - oi : N - 1 - jj));
@@ -1057,18 +1057,19 @@ __global__ __launch_bounds__(64) void k_augment(AugTables tb, const float *in_s,
     };
     for (int idx = lane; idx < NIN; idx += 64) os[idx] = is[(idx / HW) * HW + src(idx % HW)];
     for (int a = lane; a < A; a += 64) op[a] = ip[src(a)];
-  } else {
+  } else {  // a square board of BC x BC boxes, WD x WD dots (az_augment_samples refuses the others, as the reference's flip does)
+    constexpr int BC = GT::BC, WD = GT::WD, NH = GT::NH;
     for (int idx = lane; idx < NIN; idx += 64) {
-      const int c = idx / HW, cell = idx % HW, r = cell >> 2, col = cell & 3;
+      const int c = idx / HW, cell = idx % HW, r = cell / WD, col = cell % WD;
       float v = 0.0f;
       if (c == GT::CIN - 1) v = is[idx];
       else {
         const int blk = c / 3, ch = c % 3;
         if (ch == 2) {
-          if (r < 3 && col < 3) { const int b = tb.invBox[t][r * 3 + col]; v = is[(blk * 3 + 2) * HW + (b / 3) * 4 + b % 3]; }
-        } else if (ch == 0 ? col < 3 : r < 3) {
-          const int a = tb.invEdge[t][ch == 0 ? r * 3 + col : 12 + r * 4 + col];
-          v = a < 12 ? is[(blk * 3) * HW + (a / 3) * 4 + a % 3] : is[(blk * 3 + 1) * HW + ((a - 12) / 4) * 4 + (a - 12) % 4];
+          if (r < BC && col < BC) { const int b = tb.invBox[t][r * BC + col]; v = is[(blk * 3 + 2) * HW + (b / BC) * WD + b % BC]; }
+        } else if (ch == 0 ? col < BC : r < BC) {
+          const int a = tb.invEdge[t][ch == 0 ? r * BC + col : NH + r * WD + col];
+          v = a < NH ? is[(blk * 3) * HW + (a / BC) * WD + a % BC] : is[(blk * 3 + 1) * HW + ((a - NH) / WD) * WD + (a - NH) % WD];
         }
       }
       os[idx] = v;
@@ -1300,7 +1301,15 @@ struct DeviceGuard {
   do {                                                                                      \
     switch ((e)->cfg.game) {                                                                \
       case AZ_GAME_TICTACTOE: { using GT = az::TicTacToe; BODY; } break;                    \
-      case AZ_GAME_DAB: { using GT = az::Dab; BODY; } break;                                \
+      case AZ_GAME_DAB:  /* examples/dots_and_boxes/game.py:24-25 BOX_ROWS x BOX_COLS, 2 .. 5 each */ \
+        switch ((e)->cfg.board_size * 8 + (e)->cfg.board_cols) {                            \
+          AZ_DAB_CASE(2, 2, BODY) AZ_DAB_CASE(2, 3, BODY) AZ_DAB_CASE(2, 4, BODY) AZ_DAB_CASE(2, 5, BODY) \
+          AZ_DAB_CASE(3, 2, BODY) AZ_DAB_CASE(3, 4, BODY) AZ_DAB_CASE(3, 5, BODY)           \
+          AZ_DAB_CASE(4, 2, BODY) AZ_DAB_CASE(4, 3, BODY) AZ_DAB_CASE(4, 4, BODY) AZ_DAB_CASE(4, 5, BODY) \
+          AZ_DAB_CASE(5, 2, BODY) AZ_DAB_CASE(5, 3, BODY) AZ_DAB_CASE(5, 4, BODY) AZ_DAB_CASE(5, 5, BODY) \
+          default: { using GT = az::Dab<3, 3>; BODY; } break;                               \
+        }                                                                                   \
+        break;                                                                              \
       default:  /* gomoku N x N: examples/gomoku/game.py's BOARD_SIZE, any value 3 .. 15 */       \
         switch ((e)->cfg.board_size) {                                                      \
           AZ_GOMOKU_CASE(3, BODY) AZ_GOMOKU_CASE(4, BODY) AZ_GOMOKU_CASE(5, BODY)           \
@@ -1314,6 +1323,7 @@ struct DeviceGuard {
   } while (0)
 // (variadic: by the time BODY arrives here its own macros are expanded and their commas stand at the top level)
 #define AZ_GOMOKU_CASE(NN, ...) case NN: { using GT = az::Gomoku<NN>; __VA_ARGS__; } break;
+#define AZ_DAB_CASE(RR, CC, ...) case RR * 8 + CC: { using GT = az::Dab<RR, CC>; __VA_ARGS__; } break;
 
 template <class GT>
 static void fill_dims(az_dims &d) {
@@ -1339,6 +1349,11 @@ int az_create(const az_config *cfg, az_engine **out) {
   *out = nullptr;
   if (cfg->game < AZ_GAME_TICTACTOE || cfg->game > AZ_GAME_GOMOKU) { g_create_err = "unknown game"; return AZ_EINVAL; }
   const int win = cfg->win_length == 0 ? 5 : cfg->win_length;  // examples/gomoku/game.py:22
+  // dots-and-boxes: board_size = BOX_ROWS (0 = the reference's 3), board_cols = BOX_COLS (0 = the same as the rows)
+  const int dab_rows = cfg->board_size == 0 ? 3 : cfg->board_size, dab_cols = cfg->board_cols == 0 ? dab_rows : cfg->board_cols;
+  if (cfg->game == AZ_GAME_DAB && (dab_rows < 2 || dab_rows > 5 || dab_cols < 2 || dab_cols > 5)) {
+    g_create_err = "dots-and-boxes: board_size (BOX_ROWS; 0 = 3) and board_cols (BOX_COLS; 0 = the rows) 2 .. 5"; return AZ_EINVAL;
+  }
   if (cfg->game == AZ_GAME_GOMOKU && (cfg->board_size < 3 || cfg->board_size > 15 || win < 3 || win > 6 || win > cfg->board_size)) {
     g_create_err = "gomoku: board_size 3 .. 15, win_length 3 .. 6 (0 = 5) and <= board_size"; return AZ_EINVAL;
   }
@@ -1354,6 +1369,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   az_engine *e = new az_engine();
   e->cfg = *cfg;
   e->cfg.win_length = win;
+  if (cfg->game == AZ_GAME_DAB) { e->cfg.board_size = dab_rows; e->cfg.board_cols = dab_cols; }
   memset(&e->dims, 0, sizeof(e->dims));
   AZ_DISPATCH(e, fill_dims<GT>(e->dims));
   az_dims &d = e->dims;
@@ -1709,26 +1725,28 @@ int az_copy_to_host(void *dst_pinned_host, const void *src_dev, uint64_t bytes, 
 static void dab_rot(int &r, int &c, int k, int n) {  // examples/dots_and_boxes/game.py:305-313 on an n x n grid
   for (int q = 0; q < (k & 3); ++q) { const int nr = n - 1 - c, nc = r; r = nr; c = nc; }
 }
-static AugTables make_aug_tables() {
+static AugTables make_aug_tables(int B) {  // B x B boxes, D x D dots
   AugTables tb;
+  memset(&tb, 0, sizeof(tb));
+  const int D = B + 1, NH = D * B;
   for (int t = 0; t < 8; ++t) {
     const int k = t >> 1;
     const bool flip = t & 1;
-    for (int a = 0; a < 24; ++a) {  // _transform_edge :261-292
-      const bool hz = a < 12;
-      int r1 = hz ? a / 3 : (a - 12) / 4, c1 = hz ? a % 3 : (a - 12) % 4;
+    for (int a = 0; a < 2 * NH; ++a) {  // _transform_edge :261-292
+      const bool hz = a < NH;
+      int r1 = hz ? a / B : (a - NH) / D, c1 = hz ? a % B : (a - NH) % D;
       int r2 = hz ? r1 : r1 + 1, c2 = hz ? c1 + 1 : c1;
-      dab_rot(r1, c1, k, 4);
-      dab_rot(r2, c2, k, 4);
+      dab_rot(r1, c1, k, D);
+      dab_rot(r2, c2, k, D);
       if (flip) { int x = r1; r1 = c1; c1 = x; x = r2; r2 = c2; c2 = x; }
-      const int na = (r1 == r2) ? r1 * 3 + (c1 < c2 ? c1 : c2) : 12 + (r1 < r2 ? r1 : r2) * 4 + c1;
+      const int na = (r1 == r2) ? r1 * B + (c1 < c2 ? c1 : c2) : NH + (r1 < r2 ? r1 : r2) * D + c1;
       tb.invEdge[t][na] = (uint8_t)a;
     }
-    for (int b = 0; b < 9; ++b) {  // _transform_box :294-303
-      int r = b / 3, c = b % 3;
-      dab_rot(r, c, k, 3);
+    for (int b = 0; b < B * B; ++b) {  // _transform_box :294-303
+      int r = b / B, c = b % B;
+      dab_rot(r, c, k, B);
       if (flip) { const int x = r; r = c; c = x; }
-      tb.invBox[t][r * 3 + c] = (uint8_t)b;
+      tb.invBox[t][r * B + c] = (uint8_t)b;
     }
   }
   return tb;
@@ -1741,7 +1759,11 @@ int az_augment_samples(az_engine *e, int32_t n, const float *states_dev, const f
   DeviceGuard guard(e->cfg.device);
   if (ring_capacity < 0 || ring_write_idx < 0 || (ring_capacity > 0 && ring_capacity < 8)) { e->err = "bad ring arguments"; return AZ_EINVAL; }
   if (n == 0) return AZ_OK;
-  static const AugTables tb = make_aug_tables();
+  if (e->cfg.game == AZ_GAME_DAB && e->cfg.board_size != e->cfg.board_cols) {  // examples/dots_and_boxes/game.py:318-319 raises too
+    e->err = "az_augment_samples: the dots-and-boxes symmetries need a square board (BOX_ROWS == BOX_COLS)"; return AZ_EINVAL;
+  }
+  static const AugTables tbs[4] = {make_aug_tables(2), make_aug_tables(3), make_aug_tables(4), make_aug_tables(5)};
+  const AugTables &tb = tbs[e->cfg.game == AZ_GAME_DAB ? e->cfg.board_size - 2 : 1];
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_augment<GT>), dim3(n, 8), dim3(64), 0, (hipStream_t)stream, tb, states_dev, pis_dev, z_dev,
                                     out_states_dev, out_pis_dev, out_z_dev, (long long)ring_capacity, (long long)ring_write_idx));
   return launch_check(e, "k_augment");

@@ -6,7 +6,7 @@
 //
 // Reference semantics (files under the reference tree):
 //   tictactoe  examples/tictactoe/game.py:20-77
-//   dab        examples/dots_and_boxes/game.py:36-156   (3x3 boxes, 4x4 dots)
+//   dab        examples/dots_and_boxes/game.py:36-156   (BOX_ROWS x BOX_COLS boxes, 2 .. 5 each; 3 x 3 as shipped)
 //   gomoku     examples/gomoku/game.py:24-104
 //   terminal value  games/base.py:104-114
 #pragma once
@@ -78,82 +78,94 @@ struct TicTacToe {
 };
 
 // ------------------------------------------------------------------------------------------
-// Dots and boxes: word0 bit a = edge of action a (a<12 horizontal r=a/3,c=a%3; else vertical
-// idx=a-12, r=idx/4, c=idx%4); word1 bits 0-8 boxes owned by PLAYER1 (box = r*3+c), bits 9-17 PLAYER2.
+// Dots and boxes with R x C boxes (examples/dots_and_boxes/game.py:24-25 BOX_ROWS, BOX_COLS; 3 x 3 in the reference as
+// shipped, any 2 .. 5 here): words [0,EW) bit a = edge of action a (a < NH horizontal r=a/C, c=a%C; else vertical
+// idx=a-NH, r=idx/(C+1), c=idx%(C+1)); then the owners: bits [0,B) boxes of PLAYER1 (box = r*C+c), bits [OB,OB+B) PLAYER2
+// (OB = B in one word while 2B <= 32, else a word each).  3 x 3: word0 = 24 edges, word1 = 9 + 9 owner bits.
+template <int R, int C>
 struct Dab {
-  static constexpr int A = 24, SW = 2, CS = 3, H = 4, WD = 4, HW = 16, CIN = 25, PMAX = 24;
+  static constexpr int BR = R, BC = C, NH = (R + 1) * C, NV = R * (C + 1), A = NH + NV, B = R * C;
+  static constexpr int EW = (A + 31) / 32, OW = (2 * B <= 32) ? 1 : 2, OB = (2 * B <= 32) ? B : 32, SW = EW + OW;
+  static constexpr int CS = 3, H = R + 1, WD = C + 1, HW = H * WD, CIN = 25, PMAX = A;
+  static constexpr uint64_t ALL = (A == 64) ? ~0ull : ((1ull << A) - 1ull);
+  static constexpr uint32_t BM = (1u << B) - 1u;
 
-  __host__ __device__ static uint32_t box_mask(int b) {
-    const int br = b / 3, bc = b % 3;
-    return (1u << (br * 3 + bc)) | (1u << ((br + 1) * 3 + bc)) | (1u << (12 + br * 4 + bc)) |
-           (1u << (12 + br * 4 + bc + 1));
+  __host__ __device__ static uint64_t edges(const uint32_t *s) { return EW == 1 ? (uint64_t)s[0] : ((uint64_t)s[0] | ((uint64_t)s[EW - 1] << 32)); }
+  __host__ __device__ static uint32_t own1(const uint32_t *s) { return s[EW] & BM; }
+  __host__ __device__ static uint32_t own2(const uint32_t *s) { return (OW == 1 ? (s[EW] >> OB) : s[EW + OW - 1]) & BM; }
+  __host__ __device__ static uint64_t box_mask(int b) {
+    const int br = b / C, bc = b % C;
+    return (1ull << (br * C + bc)) | (1ull << ((br + 1) * C + bc)) | (1ull << (NH + br * (C + 1) + bc)) |
+           (1ull << (NH + br * (C + 1) + bc + 1));
   }
   // the (up to) two boxes an edge borders; -1 where there is none  (game.py:126-156)
   __host__ __device__ static void adjacent(int a, int &b1, int &b2) {
-    if (a < 12) {
-      const int r = a / 3, c = a % 3;
-      b1 = r > 0 ? (r - 1) * 3 + c : -1;
-      b2 = r < 3 ? r * 3 + c : -1;
+    if (a < NH) {
+      const int r = a / C, c = a % C;
+      b1 = r > 0 ? (r - 1) * C + c : -1;
+      b2 = r < R ? r * C + c : -1;
     } else {
-      const int idx = a - 12, r = idx / 4, c = idx % 4;
-      b1 = c > 0 ? r * 3 + c - 1 : -1;
-      b2 = c < 3 ? r * 3 + c : -1;
+      const int idx = a - NH, r = idx / (C + 1), c = idx % (C + 1);
+      b1 = c > 0 ? r * C + c - 1 : -1;
+      b2 = c < C ? r * C + c : -1;
     }
   }
-  // boxes that playing `a` completes (bit b), given edges e and owners o
-  __host__ __device__ static uint32_t completed(uint32_t e, uint32_t o, int a) {
+  // boxes that playing `a` completes (bit b), given edges e and the owned boxes of both sides
+  __host__ __device__ static uint32_t completed(uint64_t e, uint32_t owned, int a) {
     int b1, b2;
     adjacent(a, b1, b2);
-    const uint32_t e2 = e | (1u << a), owned = (o | (o >> 9)) & 0x1FFu;
+    const uint64_t e2 = e | (1ull << a);
     uint32_t done = 0;
     if (b1 >= 0 && !((owned >> b1) & 1u) && (e2 & box_mask(b1)) == box_mask(b1)) done |= 1u << b1;
     if (b2 >= 0 && !((owned >> b2) & 1u) && (e2 & box_mask(b2)) == box_mask(b2)) done |= 1u << b2;
     return done;
   }
-  __device__ static bool legal(const uint32_t *s, int a) { return ((s[0] >> a) & 1u) == 0u; }
-  __device__ static bool same_player(const uint32_t *s, int a) { return completed(s[0], s[1], a) != 0u; }
+  __device__ static bool legal(const uint32_t *s, int a) { return bit_at(s, a) == 0u; }
+  __device__ static bool same_player(const uint32_t *s, int a) { return completed(edges(s), own1(s) | own2(s), a) != 0u; }
   __device__ static int apply(uint32_t *s, int a, int player, int lane) {
-    const uint32_t e = s[0], o = s[1];
-    const uint32_t done = completed(e, o, a);
+    const uint32_t done = completed(edges(s), own1(s) | own2(s), a);
+    const int ei = a >> 5, oi = EW + ((OW == 2 && player != 1) ? 1 : 0);
+    const uint32_t ew = s[ei] | (1u << (a & 31));
+    const uint32_t ow = s[oi] | (done << ((OW == 1 && player != 1) ? OB : 0));
     wave_sync();
     if (lane == 0) {
-      s[0] = e | (1u << a);
-      s[1] = o | (done << (player == 1 ? 0 : 9));
+      s[ei] = ew;
+      s[oi] = ow;
     }
     wave_sync();
     return done ? player : -player;
   }
   __device__ static int terminal(const uint32_t *s, int, int, int, int, int /*win*/) {
-    if ((s[0] & 0xFFFFFFu) != 0xFFFFFFu) return T_NONE;
-    const int p1 = __popc(s[1] & 0x1FFu), p2 = __popc((s[1] >> 9) & 0x1FFu);
+    if ((edges(s) & ALL) != ALL) return T_NONE;
+    const int p1 = __popc(own1(s)), p2 = __popc(own2(s));
     return p1 > p2 ? T_WIN_P1 : (p2 > p1 ? T_WIN_P2 : T_NO_WINNER);
   }
   __device__ static float plane(const uint32_t *s, int ch, int cell) {
-    const int r = cell >> 2, c = cell & 3;
-    if (ch == 0) return (c < 3) ? (float)(int)((s[0] >> (r * 3 + c)) & 1u) : 0.0f;
-    if (ch == 1) return (r < 3) ? (float)(int)((s[0] >> (12 + r * 4 + c)) & 1u) : 0.0f;
-    if (r < 3 && c < 3)
-      return (float)(int)((s[1] >> (r * 3 + c)) & 1u) - (float)(int)((s[1] >> (9 + r * 3 + c)) & 1u);
+    const int r = cell / WD, c = cell % WD;
+    if (ch == 0) return (c < C) ? (float)(int)bit_at(s, r * C + c) : 0.0f;
+    if (ch == 1) return (r < R) ? (float)(int)bit_at(s, NH + r * (C + 1) + c) : 0.0f;
+    if (r < R && c < C) return (float)(int)((own1(s) >> (r * C + c)) & 1u) - (float)(int)((own2(s) >> (r * C + c)) & 1u);
     return 0.0f;
   }
   __host__ static bool encode(const float *st, uint32_t *w, int *nmoves) {
-    w[0] = w[1] = 0; *nmoves = 0;
-    for (int r = 0; r < 4; ++r)
-      for (int c = 0; c < 4; ++c) {
-        const float h = st[r * 4 + c], v = st[16 + r * 4 + c], o = st[32 + r * 4 + c];
-        if (c < 3) { if (h == 1.0f) { w[0] |= 1u << (r * 3 + c); ++*nmoves; } else if (h != 0.0f) return false; }
+    for (int i = 0; i < SW; ++i) w[i] = 0;
+    *nmoves = 0;
+    for (int r = 0; r < H; ++r)
+      for (int c = 0; c < WD; ++c) {
+        const float h = st[r * WD + c], v = st[HW + r * WD + c], o = st[2 * HW + r * WD + c];
+        if (c < C) { if (h == 1.0f) { const int a = r * C + c; w[a >> 5] |= 1u << (a & 31); ++*nmoves; } else if (h != 0.0f) return false; }
         else if (h != 0.0f) return false;
-        if (r < 3) { if (v == 1.0f) { w[0] |= 1u << (12 + r * 4 + c); ++*nmoves; } else if (v != 0.0f) return false; }
+        if (r < R) { if (v == 1.0f) { const int a = NH + r * (C + 1) + c; w[a >> 5] |= 1u << (a & 31); ++*nmoves; } else if (v != 0.0f) return false; }
         else if (v != 0.0f) return false;
-        if (r < 3 && c < 3) {
-          if (o == 1.0f) w[1] |= 1u << (r * 3 + c);
-          else if (o == -1.0f) w[1] |= 1u << (9 + r * 3 + c);
+        if (r < R && c < C) {
+          if (o == 1.0f) w[EW] |= 1u << (r * C + c);
+          else if (o == -1.0f) { if (OW == 1) w[EW] |= 1u << (OB + r * C + c); else w[EW + 1] |= 1u << (r * C + c); }
           else if (o != 0.0f) return false;
         } else if (o != 0.0f) return false;
       }
     return true;
   }
-  __host__ static bool host_won(const uint32_t *, int /*win*/ = 0) { return false; }  // terminal only when all 24 edges are drawn (ply == PMAX)
+  __host__ static bool host_won(const uint32_t *, int /*win*/ = 0) { return false; }  // terminal only when every edge is drawn (ply == PMAX)
 };
 
 // ------------------------------------------------------------------------------------------

@@ -183,7 +183,6 @@ __global__ __launch_bounds__(256, 2) void k_tower_h1(const float *__restrict__ x
                                                      void *__restrict__ feat, int FS, int feat16, unsigned int *tickets, int *overflow) {
   typedef typename E::T T;
   typedef typename E::v8 v8;
-  typedef typename E::v4 v4;
   typedef typename E::v2 v2;
   constexpr float SA = E::SA;
   constexpr int WL_BYTES = 9 * 2 * 4 * 1024;  // one 64 -> 64 layer's packed weights

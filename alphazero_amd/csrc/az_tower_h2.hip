@@ -43,7 +43,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int C = 64;                 // trunk width
 constexpr int ROW = 2 * C * 2 + 16;   // bytes of one cell's row: [half 0: 64 f16][half 1: 64 f16] + 16 B of padding
 constexpr float SA = 16.0f;           // activations are stored x SA
-constexpr float ACT_MAX = 65504.0f / SA;
 
 template <int N>
 struct Geo {

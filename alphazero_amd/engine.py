@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from typing import Optional
 from dataclasses import dataclass
 
 import torch
@@ -22,7 +23,7 @@ _NN_DTYPES = {torch.float32: NN_F32, torch.bfloat16: NN_BF16, torch.float16: NN_
 class AzConfig(C.Structure):
     _fields_ = [("game", C.c_int32), ("board_size", C.c_int32), ("n_slots", C.c_int32), ("max_sims", C.c_int32),
                 ("c_puct", C.c_float), ("epsilon", C.c_float), ("nn_dtype", C.c_int32), ("device", C.c_int32),
-                ("edge_cap", C.c_int32), ("leaves_per_step", C.c_int32), ("win_length", C.c_int32)]
+                ("edge_cap", C.c_int32), ("leaves_per_step", C.c_int32), ("win_length", C.c_int32), ("board_cols", C.c_int32)]
 
 
 class AzDims(C.Structure):
@@ -175,12 +176,15 @@ def _ptr(t):
 class Engine:
     """Many concurrent games, one search tree each, resident on one GPU."""
 
-    def __init__(self, game: int, n_slots: int, max_sims: int, board_size: int = 15, c_puct: float = 1.0,
+    def __init__(self, game: int, n_slots: int, max_sims: int, board_size: Optional[int] = None, c_puct: float = 1.0,
                  epsilon: float = 0.25, nn_dtype: torch.dtype = torch.float32, device=None, edge_cap: int = 0,
-                 leaves_per_step: int = 1, virtual_loss: float = 0.3, win_length: int = 5):
+                 leaves_per_step: int = 1, virtual_loss: float = 0.3, win_length: int = 5, board_cols: int = 0):
         """leaves_per_step K > 1: virtual loss / in-tree leaf batching (select_wave / expand_wave); the per-simulation
-        batch then has n_slots * K rows (``rows``).  Gomoku: board_size 3 .. 15 and win_length 3 .. 6 are the reference's
-        BOARD_SIZE / WIN_LENGTH constants (examples/gomoku/game.py:21-22)."""
+        batch then has n_slots * K rows (``rows``).  Gomoku: board_size 3 .. 15 (default 15) and win_length 3 .. 6 are the
+        reference's BOARD_SIZE / WIN_LENGTH constants (examples/gomoku/game.py:21-22).  Dots-and-boxes: board_size x board_cols =
+        BOX_ROWS x BOX_COLS (examples/dots_and_boxes/game.py:24-25), 2 .. 5 each; default 3 x 3, board_cols 0 = square."""
+        if board_size is None or (game != GAME_GOMOKU and board_size > 5):  # (older callers passed the gomoku default for every game)
+            board_size = 15 if game == GAME_GOMOKU else 3
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: the engine has no CPU path")
@@ -191,7 +195,7 @@ class Engine:
         self.device = torch.device("cuda", dev_index)
         self.nn_dtype = nn_dtype
         cfg = AzConfig(game, board_size, n_slots, max_sims, c_puct, epsilon, _NN_DTYPES[nn_dtype], dev_index,
-                       edge_cap, leaves_per_step, win_length)
+                       edge_cap, leaves_per_step, win_length, board_cols)
         self.win_length = win_length
         h = C.c_void_p()
         with torch.cuda.device(self.device):

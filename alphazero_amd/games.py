@@ -155,24 +155,25 @@ def gomoku_game(board_size: int, win_length: int = 5):
 
 
 class DotsAndBoxesGame(BaseGame):
-    """examples/dots_and_boxes/game.py: 3x3 boxes; state (3,4,4) = horizontal edges, vertical edges,
-    box owners; action a<12: horizontal edge (a//3, a%3), else vertical edge ((a-12)//4, (a-12)%4);
-    completing a box keeps the turn."""
+    """examples/dots_and_boxes/game.py: BOX_ROWS x BOX_COLS boxes (3 x 3 as shipped); state (3, BOX_ROWS + 1, BOX_COLS + 1) =
+    horizontal edges, vertical edges, box owners; action a < H_EDGE_COUNT: horizontal edge (a // BOX_COLS, a % BOX_COLS), else
+    vertical edge (idx // DOT_COLS, idx % DOT_COLS); completing a box keeps the turn."""
     BOX_ROWS = BOX_COLS = 3
     NUM_ACTION = 24
     AZ_GAME = (GAME_DAB, 3)
 
-    @staticmethod
-    def initial_state() -> torch.Tensor:
-        return torch.zeros((3, 4, 4), dtype=torch.float32)
+    @classmethod
+    def initial_state(cls) -> torch.Tensor:
+        return torch.zeros((3, cls.BOX_ROWS + 1, cls.BOX_COLS + 1), dtype=torch.float32)
 
-    @staticmethod
-    def _edge(action: int):
-        return (0, action // 3, action % 3) if action < 12 else (1, (action - 12) // 4, (action - 12) % 4)
+    @classmethod
+    def _edge(cls, action: int):
+        nh, bc = (cls.BOX_ROWS + 1) * cls.BOX_COLS, cls.BOX_COLS
+        return (0, action // bc, action % bc) if action < nh else (1, (action - nh) // (bc + 1), (action - nh) % (bc + 1))
 
     @classmethod
     def next_state(cls, state: torch.Tensor, action: int, player: int):
-        if not 0 <= action < 24:
+        if not 0 <= action < cls.NUM_ACTION:
             raise ValueError("action out of range")
         ch, r, c = cls._edge(action)
         if state[ch, r, c].item() != 0:
@@ -182,24 +183,39 @@ class DotsAndBoxesGame(BaseGame):
         boxes = [(r - 1, c), (r, c)] if ch == 0 else [(r, c - 1), (r, c)]
         took = False
         for br, bc in boxes:
-            if 0 <= br < 3 and 0 <= bc < 3 and nxt[2, br, bc].item() == 0 and \
+            if 0 <= br < cls.BOX_ROWS and 0 <= bc < cls.BOX_COLS and nxt[2, br, bc].item() == 0 and \
                     min(nxt[0, br, bc], nxt[0, br + 1, bc], nxt[1, br, bc], nxt[1, br, bc + 1]).item() != 0:
                 nxt[2, br, bc] = float(player)
                 took = True
         return nxt, (player if took else -player)
 
-    @staticmethod
-    def legal_action_mask(state: torch.Tensor) -> torch.Tensor:
-        return torch.cat([(state[0, :4, :3] == 0).reshape(-1), (state[1, :3, :4] == 0).reshape(-1)]).float().view(1, 24)
+    @classmethod
+    def legal_action_mask(cls, state: torch.Tensor) -> torch.Tensor:
+        r, c = cls.BOX_ROWS, cls.BOX_COLS
+        return torch.cat([(state[0, :r + 1, :c] == 0).reshape(-1), (state[1, :r, :c + 1] == 0).reshape(-1)]).float().view(1, cls.NUM_ACTION)
 
-    @staticmethod
-    def is_terminal(state: torch.Tensor) -> bool:
-        return int(state[0, :4, :3].sum() + state[1, :3, :4].sum()) == 24
+    @classmethod
+    def is_terminal(cls, state: torch.Tensor) -> bool:
+        r, c = cls.BOX_ROWS, cls.BOX_COLS
+        return int(state[0, :r + 1, :c].sum() + state[1, :r, :c + 1].sum()) == cls.NUM_ACTION
 
     @classmethod
     def _get_winner(cls, state: torch.Tensor):
         if not cls.is_terminal(state):
             return None
-        own = state[2, :3, :3]
+        own = state[2, :cls.BOX_ROWS, :cls.BOX_COLS]
         p1, p2 = int((own == PLAYER1).sum()), int((own == PLAYER2).sum())
         return PLAYER1 if p1 > p2 else (PLAYER2 if p2 > p1 else None)
+
+
+def dots_and_boxes_game(box_rows: int, box_cols: int = 0):
+    """DotsAndBoxesGame with the reference's two constants set (examples/dots_and_boxes/game.py:24-25 BOX_ROWS, BOX_COLS): any
+    board of 2 .. 5 by 2 .. 5 boxes has a native rule kernel (az::Dab<R, C>)."""
+    r = int(box_rows)
+    c = int(box_cols) or r
+    if not (2 <= r <= 5 and 2 <= c <= 5):
+        raise ValueError("dots_and_boxes_game: box_rows and box_cols 2 .. 5")
+    if (r, c) == (3, 3):
+        return DotsAndBoxesGame
+    return type(f"DotsAndBoxes{r}x{c}Game", (DotsAndBoxesGame,),
+                {"BOX_ROWS": r, "BOX_COLS": c, "NUM_ACTION": (r + 1) * c + r * (c + 1), "AZ_GAME": (GAME_DAB, r)})

@@ -14,7 +14,7 @@ from typing import Optional
 
 import torch
 
-from .arena import C_PUCT, EPSILON, TRAIN_NUM_SIMULATION, resolve_game, resolve_win_length
+from .arena import C_PUCT, EPSILON, TRAIN_NUM_SIMULATION, engine_constants, resolve_game
 from .engine import Engine, EngineError
 
 
@@ -32,7 +32,7 @@ def play_match(game_cls, model_a: torch.nn.Module, model_b: torch.nn.Module, n_g
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     game_id, board = resolve_game(game_cls)
     eng = Engine(game_id, n_games, num_simulation, board_size=board, c_puct=c_puct, epsilon=EPSILON, device=dev,
-                 win_length=resolve_win_length(game_cls))
+                 **engine_constants(game_cls))
     d = eng.dims
     A = d.n_action
     models = (model_a.to(dev).eval(), model_b.to(dev).eval())

@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from .arena import ALPHA, C_PUCT, EPSILON, TRAIN_NUM_SIMULATION, resolve_game, resolve_win_length
+from .arena import ALPHA, C_PUCT, EPSILON, TRAIN_NUM_SIMULATION, engine_constants, resolve_game, resolve_win_length
 from .engine import Engine, EngineError
 
 
@@ -21,6 +21,7 @@ class MCTS:
         self.game_cls = game_cls
         self.game_id, self.board_size = resolve_game(game_cls)
         self.win_length = resolve_win_length(game_cls)
+        self._constants = engine_constants(game_cls)
         self.device = torch.device(device) if device is not None else None
         self._engines: dict = {}
 
@@ -28,7 +29,7 @@ class MCTS:
         key = (num_simulation, float(c_puct), str(device))
         if key not in self._engines:
             self._engines[key] = Engine(self.game_id, 1, num_simulation, board_size=self.board_size, c_puct=c_puct,
-                                        epsilon=EPSILON, device=device, win_length=self.win_length)
+                                        epsilon=EPSILON, device=device, **self._constants)
         return self._engines[key]
 
     def search(self, model: torch.nn.Module, root_state: torch.Tensor, root_player: int,

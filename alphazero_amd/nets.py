@@ -60,14 +60,17 @@ class TicTacToeNet(DualHeadNet):
 
 
 class DotsAndBoxesNet(DualHeadNet):
-    """(B,25,4,4) -> (B,24),(B,1); 53,532 parameters."""
+    """(B,25,4,4) -> (B,24),(B,1); 53,532 parameters.  box_rows / box_cols: the reference's model reads its plane size and action
+    count from the game class's constants (examples/dots_and_boxes/model.py:27-29, :44) -- the same network for another board."""
 
-    def __init__(self) -> None:
+    def __init__(self, box_rows: int = 3, box_cols: int = 0) -> None:
         super().__init__()
-        c, hw = 64, 16
+        r = int(box_rows)
+        cc = int(box_cols) or r
+        c, hw, n_action = 64, (r + 1) * (cc + 1), (r + 1) * cc + r * (cc + 1)
         self._shared_layers = nn.Sequential(nn.Conv2d(HISTORY_LEN * 3 + 1, c, 3, padding=1), nn.ReLU(),
                                             nn.Conv2d(c, c, 3, padding=1), nn.ReLU())
-        self._policy_head = nn.Sequential(nn.Conv2d(c, 2, 1), nn.ReLU(), nn.Flatten(1), nn.Linear(2 * hw, 24))
+        self._policy_head = nn.Sequential(nn.Conv2d(c, 2, 1), nn.ReLU(), nn.Flatten(1), nn.Linear(2 * hw, n_action))
         self._value_head = nn.Sequential(nn.Conv2d(c, 1, 1), nn.ReLU(), nn.Flatten(1), *_mlp_value(hw))
 
 

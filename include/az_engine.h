@@ -43,7 +43,8 @@ typedef struct az_engine az_engine;
 
 typedef struct az_config {
   int32_t game;        /* AZ_GAME_* */
-  int32_t board_size;  /* gomoku N = examples/gomoku/game.py:21 BOARD_SIZE, 3 .. 15; ignored otherwise */
+  int32_t board_size;  /* gomoku N = examples/gomoku/game.py:21 BOARD_SIZE, 3 .. 15; dots-and-boxes: BOX_ROWS
+                          (examples/dots_and_boxes/game.py:24), 2 .. 5, 0 = the reference's 3; ignored for tic-tac-toe */
   int32_t n_slots;     /* concurrent games (one tree each) */
   int32_t max_sims;    /* simulations per move the trees are sized for (TRAIN_NUM_SIMULATION) */
   float c_puct;        /* config/basic.py:12 */
@@ -56,6 +57,8 @@ typedef struct az_config {
                               az_expand_wave -- the per-simulation batch then has n_slots * leaves_per_step rows */
   int32_t win_length;  /* gomoku: stones in a row that win = examples/gomoku/game.py:22 WIN_LENGTH, 3 .. 6 and <= board_size;
                           0 = the reference's 5; ignored otherwise */
+  int32_t board_cols;  /* dots-and-boxes: BOX_COLS (examples/dots_and_boxes/game.py:25), 2 .. 5, 0 = the same as board_size;
+                          ignored otherwise */
 } az_config;
 
 typedef struct az_dims {

@@ -72,6 +72,24 @@ class win_length:
         return False
 
 
+class box_shape:
+    """``with box_shape(rows, cols):`` the oracle's dots-and-boxes code runs with the reference's BOX_ROWS / BOX_COLS constants
+    (examples/dots_and_boxes/game.py:24-25) set to rows x cols (2 .. 5 each) -- process-wide, restored on exit."""
+
+    def __init__(self, rows: int, cols: int):
+        self.r, self.c, self.old = int(rows), int(cols), None
+
+    def __enter__(self):
+        if not (2 <= self.r <= 5 and 2 <= self.c <= 5):
+            raise ValueError("BOX_ROWS, BOX_COLS 2 .. 5")
+        self.old = lib().az_oracle_set_box_shape(self.r, self.c)
+        return self
+
+    def __exit__(self, *exc):
+        lib().az_oracle_set_box_shape(self.old // 8, self.old % 8)
+        return False
+
+
 def dims(game: int, board_size: int = 15) -> dict:
     out = (C.c_int * 6)()
     if lib().az_oracle_dims(game, board_size, out) != 0:

@@ -737,6 +737,100 @@ def make_mnk():
         GomokuGame.BOARD_SIZE, GomokuGame.WIN_LENGTH = 15, 5
 
 
+DAB_SHAPES = [(2, 2), (4, 4), (5, 5), (2, 3), (3, 2), (4, 5), (5, 4), (3, 5)]  # (BOX_ROWS, BOX_COLS): examples/dots_and_boxes/game.py:24-25
+
+
+def set_box_shape(r, c):
+    """the reference's class constants (examples/dots_and_boxes/game.py:24-34), all of them: the derived ones are computed once,
+    in the class body"""
+    G = DotsAndBoxesGame
+    G.BOX_ROWS, G.BOX_COLS, G.DOT_ROWS, G.DOT_COLS = r, c, r + 1, c + 1
+    G.H_EDGE_COUNT, G.V_EDGE_COUNT = (r + 1) * c, r * (c + 1)
+    G.NUM_ACTION = G.H_EDGE_COUNT + G.V_EDGE_COUNT
+    G.STATE_SHAPE = (3, r + 1, c + 1)
+
+
+def make_dab_shapes():
+    """the reference's own DotsAndBoxesGame / DotsAndBoxesModel / MCTS / ChessArena with BOX_ROWS x BOX_COLS changed: rule
+    games for every pair of DAB_SHAPES, searches and one self-play game on some, the 8 symmetries on the square ones"""
+    try:
+        for r, c in DAB_SHAPES:
+            set_box_shape(r, c)
+            nh, A = (r + 1) * c, (r + 1) * c + r * (c + 1)
+            double = [0, 1, c, c + 1, nh, nh + 2, nh + 1]  # boxes (0,0) and (0,1): every other edge first, then V(0,1) takes both
+            rules_fixture(f"dab{r}x{c}", DotsAndBoxesGame, [double, list(range(A)), list(range(A - 1, -1, -1))], 20, 1200 + 8 * r + c)
+        rng = np.random.default_rng(12)
+        cases = []
+        for j, (r, c, specs) in enumerate([(2, 2, [(0, 60, True), (5, 100, True), (9, 60, False)]),
+                                           (4, 4, [(0, 80, True), (20, 80, True), (34, 120, False)]),
+                                           (2, 3, [(3, 80, True), (12, 80, False)]),
+                                           (5, 5, [(10, 60, True), (52, 100, True)]),
+                                           (4, 5, [(30, 80, True)])]):
+            set_box_shape(r, c)
+            torch.manual_seed(720 + j)
+            model = DotsAndBoxesModel().eval()
+            for i, (nm, ns, ud) in enumerate(specs):
+                cs = search_case(DotsAndBoxesGame, model, nm, ns, ud, rng, 900 + 10 * j + i)
+                cases.append((f"dab{r}x{c}_{i}", cs))
+                print("search", cases[-1][0], "moves", nm, "sims", ns, "maxdepth", cs["trace"][:, 0].max())
+        out = {"tags": np.array([t for t, _ in cases])}
+        for t, cs in cases:
+            for kk, v in cs.items():
+                out[f"{t}__{kk}"] = v
+        np.savez_compressed(os.path.join(OUT, "search_dab.npz"), **out)
+
+        cases = []
+        for r, c, sims, tao, seed in ((2, 2, 30, 1.0, 31), (3, 2, 25, 0.7, 32)):
+            set_box_shape(r, c)
+            cases.append((f"dab{r}x{c}_0", dedup_evals(selfplay_case(DotsAndBoxesGame, DotsAndBoxesModel, sims, tao, seed, 730 + r))))
+        out = {"tags": np.array([t for t, _ in cases])}
+        for t, cs in cases:
+            print("selfplay", t, "plies", int(cs["plies"]), "evals", len(cs["eval_in"]))
+            for kk, v in cs.items():
+                out[f"{t}__{kk}"] = v
+        np.savez_compressed(os.path.join(OUT, "selfplay_dab.npz"), **out)
+
+        rng = np.random.default_rng(98)
+        out, tags = {}, []
+        for b in (2, 4, 5):
+            set_box_shape(b, b)
+            d, A, n = b + 1, 2 * b * (b + 1), 5
+            st = np.zeros((n, 25, d, d), np.float32)
+            for blk in range(8):  # only legal cells are ever non-zero; edges are 0/1
+                st[:, 3 * blk, :, :b] = rng.integers(0, 2, size=(n, d, b))
+                st[:, 3 * blk + 1, :b, :] = rng.integers(0, 2, size=(n, b, d))
+                st[:, 3 * blk + 2, :b, :b] = rng.integers(-1, 2, size=(n, b, b))
+            st[:, -1] = rng.choice([-1.0, 1.0], size=(n, 1, 1))
+            pi = rng.random((n, A)).astype(np.float32)
+            z = rng.choice([-1.0, 0.0, 1.0], size=n).astype(np.float32)
+            outs_s, outs_p, outs_z = [], [], []
+            for i in range(n):
+                res = DotsAndBoxesGame.get_enhanced_data(torch.from_numpy(st[i:i + 1]), torch.from_numpy(pi[i:i + 1]), torch.tensor([z[i]]))
+                assert len(res) == 8
+                for s_, p_, z_ in res:
+                    outs_s.append(s_.reshape(-1).numpy().copy())
+                    outs_p.append(p_.reshape(-1).numpy().copy())
+                    outs_z.append(float(z_.reshape(-1)[0]))
+            tag = f"dab{b}x{b}"
+            tags.append(tag)
+            out[f"{tag}__in_states"], out[f"{tag}__in_pis"], out[f"{tag}__in_z"] = st.astype(np.int8), pi, z
+            out[f"{tag}__out_states"] = np.array(outs_s).astype(np.int8)
+            out[f"{tag}__out_pis"] = np.array(outs_p, np.float32)
+            out[f"{tag}__out_z"] = np.array(outs_z, np.float32)
+            print("augment", tag, n, "samples")
+        out["tags"] = np.array(tags)
+        np.savez_compressed(os.path.join(OUT, "augment_dab.npz"), **out)
+        # a non-square board has no symmetries in the reference: record what get_enhanced_data does there
+        set_box_shape(2, 3)
+        try:
+            DotsAndBoxesGame.get_enhanced_data(torch.zeros(1, 25, 3, 4), torch.zeros(1, 17), torch.zeros(1))
+            print("augment dab2x3: no error")
+        except Exception as ex:  # noqa: BLE001
+            print("augment dab2x3 raises", type(ex).__name__, ex)
+    finally:
+        set_box_shape(3, 3)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rules", "search", "selfplay", "augment", "loss", "quick"]
     if "quick" in which:
@@ -757,3 +851,5 @@ if __name__ == "__main__":
         make_ring()
     if "mnk" in which:  # gomoku under other BOARD_SIZE / WIN_LENGTH constants
         make_mnk()
+    if "dabshapes" in which:  # dots-and-boxes under other BOX_ROWS / BOX_COLS constants
+        make_dab_shapes()

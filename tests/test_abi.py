@@ -37,3 +37,7 @@ def test_create_rejects_bad_config_without_gpu():
         bad = AzConfig(2, board, 4, 10, 1.0, 0.25, 0, 0, 0, 0, win)
         assert lib.az_create(ctypes.byref(bad), ctypes.byref(h)) == -1, (board, win)
         assert b"board_size 3 .. 15" in lib.az_last_error(None)
+    for rows, cols in ((1, 3), (6, 0), (3, 6), (4, 1)):  # dots-and-boxes: BOX_ROWS, BOX_COLS 2 .. 5 (0 = 3 / the same as the rows)
+        bad = AzConfig(1, rows, 4, 10, 1.0, 0.25, 0, 0, 0, 0, 0, cols)
+        assert lib.az_create(ctypes.byref(bad), ctypes.byref(h)) == -1, (rows, cols)
+        assert b"BOX_ROWS" in lib.az_last_error(None)

@@ -101,6 +101,50 @@ def test_arena_on_a_gomoku_class_with_other_constants(oracle, n, k):
     assert pi.shape == (1, A) and abs(float(pi.sum()) - 1.0) < 1e-5 and float(pi[0, n + 1]) == 0.0
 
 
+@pytest.mark.parametrize("rows,cols", [(2, 2), (4, 3), (5, 5)])
+def test_arena_on_a_dots_and_boxes_class_with_other_constants(oracle, rows, cols):
+    """the same for the reference's DotsAndBoxesGame with BOX_ROWS / BOX_COLS edited (examples/dots_and_boxes/game.py:24-25):
+    ChessArena maps the class to az::Dab<R, C>; a seeded game replays on the oracle under the same constants, the mirror's own
+    rules replay it move for move, and the mirror network (which, like the reference's, sizes itself from the constants) runs"""
+    from alphazero_amd import games, nets
+    from alphazero_amd.arena import ChessArena
+    from alphazero_amd.mcts import MCTS
+
+    cls = games.dots_and_boxes_game(rows, cols)
+    A, sims, seed = (rows + 1) * cols + rows * (cols + 1), 30, 78
+    assert (cls.BOX_ROWS, cls.BOX_COLS, cls.NUM_ACTION) == (rows, cols, A)
+    noise, expo = _reference_draws(seed, A, A)
+    arena = ChessArena(functools.partial(HashNet, A, 5.0), cls, torch.device("cuda:0"), num_simulation=sims)
+    assert (arena.board_size, arena.board_cols) == (rows, cols)
+    pool = ListPool()
+    torch.manual_seed(seed)
+    arena.self_play(1.0, pool)
+    with oracle.box_shape(rows, cols):
+        d = oracle.dims(1, rows)
+        ev = oracle.torch_eval(HashNet(A, 5.0), (d["cin"], d["H"], d["W"]))
+        r = oracle.self_play(1, rows, sims, 1.0, expo, ev, noise=noise, max_plies=A)
+    assert len(pool.items) == r["plies"] == A
+    for j, (st, pi, z) in enumerate(pool.items):
+        t = r["plies"] - 1 - j
+        assert st.shape == (1, 25, rows + 1, cols + 1) and np.array_equal(st.numpy().reshape(-1), r["nn_states"][t])
+        assert np.array_equal(pi.numpy().reshape(-1), r["pis"][t]) and float(z[0]) == float(r["z"][t])
+    # the same game through the mirror's own rules: every recorded position, the extra turns, the result
+    g = cls()
+    for t, a in enumerate(r["actions"]):
+        assert np.array_equal(g.get_state().numpy().reshape(-1), r["nn_states"][t].reshape(25, -1)[21:24].reshape(-1))
+        assert g.get_player() == int(r["nn_states"][t].reshape(25, -1)[24, 0])
+        over = g.step(int(a))
+        assert over == (t == A - 1)
+    w = cls._get_winner(g.get_state())
+    assert (w is None) == (r["result"] == 0.0)
+    # the single-position adapter with the mirror network sized from the constants
+    net = nets.DotsAndBoxesNet(rows, cols).cuda().eval()
+    g = cls()
+    g.step(1)
+    pi = MCTS(cls).search(net, g.get_state(), g.get_player(), history_state=g.get_history(), num_simulation=20, use_Dirichlet=False)
+    assert pi.shape == (1, A) and abs(float(pi.sum()) - 1.0) < 1e-5 and float(pi[0, 1]) == 0.0
+
+
 @pytest.mark.parametrize("name,game,n,A,sims", GAMES)
 def test_mcts_search_adapter(oracle, name, game, n, A, sims):
     from alphazero_amd.mcts import MCTS

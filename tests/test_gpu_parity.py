@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from .conftest import game_of, load_cases, win_of
+from .conftest import DAB_SHAPES, cols_of, game_of, load_cases, reference_constants, win_of
 
 pytestmark = pytest.mark.gpu
 
@@ -138,6 +138,65 @@ def test_other_board_sizes_and_win_lengths_match_oracle(oracle, n, k, sims):
             assert r["plies"] == plies[g] and list(r["actions"]) == acts[g] and result[g] == r["result"], (n, k, g)
 
 
+@pytest.mark.parametrize("rows,cols", DAB_SHAPES + [(5, 2), (2, 5), (3, 4)])
+def test_other_box_shapes_match_oracle(oracle, rows, cols):
+    """dots-and-boxes with the reference's BOX_ROWS / BOX_COLS constants at other values (examples/dots_and_boxes/game.py:24-25):
+    searches from random positions up to the last few edges (extra turns, double completions, terminal leaves in the tree) and
+    whole self-play games with their emitted samples == the oracle running the same rule code with the same constants; the
+    symmetries of a non-square board are refused as the reference refuses them (:318-319)"""
+    from alphazero_amd.engine import EngineError
+
+    rng = np.random.default_rng(5000 + 8 * rows + cols)
+    G, sims = 16, 120
+    with oracle.box_shape(rows, cols):
+        d = oracle.dims(1, rows)
+        A = d["A"]
+        assert A == rows * (cols + 1) + (rows + 1) * cols and (d["H"], d["W"]) == (rows + 1, cols + 1)
+        eng = _engine(1, rows, G, sims, board_cols=cols)
+        assert (eng.dims.n_action, eng.dims.height, eng.dims.width, eng.dims.nn_channels) == (A, rows + 1, cols + 1, 25)
+        # (the first four roots two to four edges from the end: every line of play below them ends inside the tree)
+        pos = [_random_position(oracle, 1, rows, A - 2 - g % 3 if g < 4 else int(rng.integers(0, A - 1)), rng) for g in range(G)]
+        for g, (h, p) in enumerate(pos):
+            eng.set_position(g, h, p)
+        noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
+        pi, visits, q, prior = _run_search(eng, sims, lambda x, l, v: eng.eval_hash(x, l, v, 6.0), torch.from_numpy(noise_np).cuda())
+        fn, ctx, _keep = oracle.hash_eval(6.0)
+        for g, (h, p) in enumerate(pos):
+            r = oracle.search(1, rows, h[-1], p, h, sims, fn, ctx, noise=noise_np[g])
+            assert np.array_equal(visits[g], r["visits"]) and np.array_equal(pi[g], r["pi"]), (rows, cols, g)
+            assert np.array_equal(q[g], r["child_q"]) and np.array_equal(prior[g], r["root_prior"]), (rows, cols, g)
+        assert eng.read_stats()["terminals"] > 0
+        # whole games and their samples
+        eng = _engine(1, rows, 6, 24, board_cols=cols)
+        noise_tab = rng.dirichlet([0.3] * A, size=(6, A)).astype(np.float32)
+        expo_tab = rng.exponential(1.0, size=(6, A, A)).astype(np.float32)
+        acts, plies = _self_play(eng, 24, lambda x, l, v: eng.eval_hash(x, l, v, 5.0), noise_tab, expo_tab, 1.0)
+        slots = sorted(plies)
+        states, pis, z, offs = eng.emit_samples(slots, [plies[g] for g in slots])
+        _, _, _, result = eng.game_info()
+        states, pis, z, result = states.cpu().numpy(), pis.cpu().numpy(), z.cpu().numpy(), result.cpu().numpy()
+        fn, ctx, _keep = oracle.hash_eval(5.0)
+        for i, g in enumerate(slots):
+            r = oracle.self_play(1, rows, 24, 1.0, expo_tab[g], fn, ctx, noise=noise_tab[g], max_plies=A)
+            assert r["plies"] == plies[g] == A and list(r["actions"]) == acts[g] and result[g] == r["result"], (rows, cols, g)
+            lo, hi = int(offs[i]), int(offs[i + 1])
+            assert np.array_equal(states[lo:hi], r["nn_states"][::-1]) and np.array_equal(pis[lo:hi], r["pis"][::-1])
+            assert np.array_equal(z[lo:hi], r["z"][::-1])
+        if rows != cols:
+            with pytest.raises(EngineError, match="square"):
+                eng.augment_samples(torch.zeros(1, eng.dims.nn_numel, device="cuda"), torch.zeros(1, A, device="cuda"), torch.zeros(1, device="cuda"))
+        else:  # the 8 symmetries against the numpy restatement (pinned for 2, 3, 4, 5 by the reference's recorded outputs)
+            from oracle import augment as AUG
+
+            n = min(6, states.shape[0])
+            os_, op, oz = eng.augment_samples(torch.from_numpy(states[:n]).cuda(), torch.from_numpy(pis[:n]).cuda(), torch.from_numpy(z[:n]).cuda())
+            os_, op = os_.cpu().numpy(), op.cpu().numpy()
+            for i in range(n):
+                ws, wp, _ = AUG.augment_dab(states[i].reshape(25, rows + 1, cols + 1), pis[i], z[i])
+                for t in range(8):
+                    assert np.array_equal(os_[8 * i + t], ws[t].reshape(-1)) and np.array_equal(op[8 * i + t], wp[t])
+
+
 @pytest.mark.parametrize("name,game,n,sims,moves", [("gomoku15", 2, 15, 220, 0), ("gomoku15", 2, 15, 150, 40), ("gomoku9", 2, 9, 120, 3)])
 def test_deep_narrow_trees_match_oracle(oracle, name, game, n, sims, moves):
     """One-line searches: paths far longer than a wavefront is wide (the backup's second loop), a terminal leaf at the
@@ -192,17 +251,17 @@ def test_all_legal_priors_underflow_is_an_error_like_the_reference():
         eng.check()
 
 
-SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz")}
+SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz"), **load_cases("search_dab.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SEARCH))
 def test_search_matches_reference_golden(oracle, tag):
     """The reference's own recorded searches; the network is replayed from the recorded table.  (gomoku<N>k<K>: recorded with
-    the reference's BOARD_SIZE / WIN_LENGTH constants set to N / K.)"""
+    the reference's BOARD_SIZE / WIN_LENGTH constants set to N / K; dab<R>x<C>: with its BOX_ROWS / BOX_COLS set to R / C.)"""
     c = SEARCH[tag]
     game, n = game_of(tag)
     sims = int(c["num_sim"])
-    eng = _engine(game, n, 1, sims, win_length=win_of(tag))
+    eng = _engine(game, n, 1, sims, win_length=win_of(tag), board_cols=cols_of(tag))
     d = eng.dims
     eng.set_position(0, c["history"].astype(np.float32), int(c["root_player"]))
     table = {c["eval_in"][i].astype(np.float32).tobytes(): (c["eval_logits"][i], c["eval_value"][i])
@@ -285,7 +344,7 @@ def test_self_play_matches_oracle_hash_net(oracle, name, game, n, sims, tao):
         assert result[g] == r["result"]
 
 
-SELFPLAY = load_cases("selfplay.npz")
+SELFPLAY = {**load_cases("selfplay.npz"), **load_cases("selfplay_dab.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SELFPLAY))
@@ -293,7 +352,7 @@ def test_self_play_matches_reference_golden(oracle, tag):
     c = SELFPLAY[tag]
     game, n = game_of(tag)
     sims, tao = int(c["num_sim"]), float(c["tao"])
-    eng = _engine(game, n, 1, sims)
+    eng = _engine(game, n, 1, sims, board_cols=cols_of(tag))
     table = {c["eval_in"][i].astype(np.float32).tobytes(): (c["eval_logits"][i], c["eval_value"][i])
              for i in range(len(c["eval_in"]))}
 
@@ -338,16 +397,16 @@ def test_full_size_invariants():
     assert st["sims"] == G * sims and st["evals"] == G * sims
 
 
-@pytest.mark.parametrize("tag", ["tictactoe", "dab", "gomoku15", "gomoku9"])
+@pytest.mark.parametrize("tag", ["tictactoe", "dab", "gomoku15", "gomoku9", "dab2x2", "dab4x4", "dab5x5"])
 def test_augmentation_matches_reference_golden(tag):
     """az_augment_samples == the reference's get_enhanced_data (recorded), bit-exact, incl. ring wrap-around"""
     import os
 
     from .conftest import GOLDEN
 
-    z = np.load(os.path.join(GOLDEN, "augment.npz"))
+    z = np.load(os.path.join(GOLDEN, "augment_dab.npz" if "x" in tag else "augment.npz"))
     game, n = game_of(tag)
-    eng = _engine(game, n, 1, 2)
+    eng = _engine(game, n, 1, 2, board_cols=cols_of(tag))
     st = torch.from_numpy(z[f"{tag}__in_states"].astype(np.float32)).cuda()
     pi = torch.from_numpy(z[f"{tag}__in_pis"]).cuda()
     zz = torch.from_numpy(z[f"{tag}__in_z"]).cuda()

@@ -11,14 +11,15 @@ import numpy as np
 import pytest
 import torch
 
-from .conftest import GOLDEN, MNK_RULES, win_of
+from .conftest import DAB_RULES, GOLDEN, MNK_RULES, cols_of, win_of
 
 pytestmark = pytest.mark.gpu
 
 RULES = [("tictactoe", 0, 3), ("dab", 1, 3), ("gomoku15", 2, 15), ("gomoku9", 2, 9)]
 # + the full-board draw (81 plies, no five for either side: terminal, no winner, result 0; examples/gomoku/game.py:47-52)
 # + gomoku under other values of the reference's BOARD_SIZE / WIN_LENGTH constants (examples/gomoku/game.py:21-22)
-FIXTURES = RULES + [("gomoku9_draw", 2, 9)] + MNK_RULES
+# + dots-and-boxes under other values of BOX_ROWS / BOX_COLS (examples/dots_and_boxes/game.py:24-25)
+FIXTURES = RULES + [("gomoku9_draw", 2, 9)] + MNK_RULES + DAB_RULES
 
 
 def _two_sims(eng, nn, logits, values):
@@ -36,7 +37,7 @@ def test_reference_rule_cases_through_the_hip_rules(name, game, n):
 
     z = np.load(os.path.join(GOLDEN, f"rules_{name}.npz"))
     G = int(z["n_games"])
-    eng = Engine(game, G, 4, board_size=n, device="cuda:0", win_length=win_of(name))
+    eng = Engine(game, G, 4, board_size=n, device="cuda:0", win_length=win_of(name), board_cols=cols_of(name))
     d = eng.dims
     A, numel = d.n_action, d.state_numel
     nn, logits, values = eng.new_nn_input(), eng.new(G, A), eng.new(G)

@@ -10,17 +10,18 @@ import os
 import numpy as np
 import pytest
 
-from .conftest import GOLDEN, MNK_RULES, game_of, load_cases, win_of
+from .conftest import DAB_RULES, GOLDEN, MNK_RULES, game_of, load_cases, reference_constants
 
 # gomoku9_draw: a scripted 81-ply game that fills the board with no five for either side (the reference says terminal, no
 # winner, evaluation 0: examples/gomoku/game.py:47-52) -- the case random playouts never reach
 RULES = [("tictactoe", 0, 3), ("dab", 1, 3), ("gomoku15", 2, 15), ("gomoku9", 2, 9), ("gomoku9_draw", 2, 9)]
 
 
-@pytest.mark.parametrize("name,game,n", RULES + MNK_RULES)
+@pytest.mark.parametrize("name,game,n", RULES + MNK_RULES + DAB_RULES)
 def test_rules_kat(oracle, name, game, n):
-    """(the gomoku<N>k<K> fixtures: the reference's GomokuGame with its BOARD_SIZE / WIN_LENGTH constants set to N / K)"""
-    with oracle.win_length(win_of(name)):
+    """(the gomoku<N>k<K> fixtures: the reference's GomokuGame with its BOARD_SIZE / WIN_LENGTH constants set to N / K; dab<R>x<C>:
+    its DotsAndBoxesGame with BOX_ROWS x BOX_COLS = R x C)"""
+    with reference_constants(oracle, name):
         _rules_kat(oracle, name, game, n)
 
 
@@ -59,7 +60,7 @@ def _table(c):
             for i in range(len(c["eval_in"]))}
 
 
-SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz")}
+SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz"), **load_cases("search_dab.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SEARCH))
@@ -69,7 +70,7 @@ def test_search_kat(oracle, tag):
     ev = oracle.table_eval(_table(c))  # KeyError here <=> the oracle built a different NN input
     noise = c["noise"] if c["noise"].size else None
     D = c["trace"].shape[1]
-    with oracle.win_length(win_of(tag)):
+    with reference_constants(oracle, tag):
         r = oracle.search(game, n, c["root_state"].astype(np.float32), int(c["root_player"]),
                           c["history"].astype(np.float32), int(c["num_sim"]), ev, noise=noise, trace_stride=D)
     assert np.array_equal(r["visits"], c["visits"])           # bit-exact decisions
@@ -89,7 +90,7 @@ def test_search_kat_reference_priors(oracle, tag):
     game, n = game_of(tag)
     ev = oracle.table_eval(_table(c))
     noise = c["noise"] if c["noise"].size else None
-    with oracle.win_length(win_of(tag)):
+    with reference_constants(oracle, tag):
         r = oracle.search(game, n, c["root_state"].astype(np.float32), int(c["root_player"]),
                           c["history"].astype(np.float32), int(c["num_sim"]), ev, noise=noise,
                           prior_override=c["priors"], trace_stride=c["trace"].shape[1])
@@ -99,7 +100,7 @@ def test_search_kat_reference_priors(oracle, tag):
     assert np.array_equal(r["root_prior"], c["root_prior"])
 
 
-SELFPLAY = load_cases("selfplay.npz")
+SELFPLAY = {**load_cases("selfplay.npz"), **load_cases("selfplay_dab.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SELFPLAY))
@@ -107,7 +108,8 @@ def test_selfplay_kat(oracle, tag):
     c = SELFPLAY[tag]
     game, n = game_of(tag)
     ev = oracle.table_eval(_table(c))
-    r = oracle.self_play(game, n, int(c["num_sim"]), float(c["tao"]), c["expo"], ev, noise=c["noise"])
+    with reference_constants(oracle, tag):
+        r = oracle.self_play(game, n, int(c["num_sim"]), float(c["tao"]), c["expo"], ev, noise=c["noise"])
     T = int(c["plies"])
     assert r["plies"] == T
     assert np.array_equal(r["actions"], c["actions"])
@@ -132,12 +134,13 @@ def test_expf_logf_accuracy(oracle):
         assert abs(oracle.powf(x, y) - x ** y) <= 2e-5 * (x ** y) + 1e-30
 
 
-@pytest.mark.parametrize("tag", ["tictactoe", "dab", "gomoku15", "gomoku9"])
+@pytest.mark.parametrize("tag", ["tictactoe", "dab", "gomoku15", "gomoku9", "dab2x2", "dab4x4", "dab5x5"])
 def test_augmentation_kat(tag):
-    """oracle/augment.py (numpy) == the reference's get_enhanced_data on every golden sample, bit-exact"""
+    """oracle/augment.py (numpy) == the reference's get_enhanced_data on every golden sample, bit-exact (dab<B>x<B>: with
+    BOX_ROWS = BOX_COLS = B; a non-square board has no symmetries -- the reference raises, make_golden.py records that)"""
     from oracle import augment as AUG
 
-    z = np.load(os.path.join(GOLDEN, "augment.npz"))
+    z = np.load(os.path.join(GOLDEN, "augment_dab.npz" if "x" in tag else "augment.npz"))
     game, _ = game_of(tag)
     st, pi, zz = z[f"{tag}__in_states"].astype(np.float32), z[f"{tag}__in_pis"], z[f"{tag}__in_z"]
     for i in range(st.shape[0]):
