@@ -57,9 +57,29 @@ def resolve_board_cols(game_cls) -> int:
     return int(getattr(game_cls, "BOX_COLS", 0)) if hasattr(game_cls, "BOX_ROWS") else 0
 
 
+def resolve_history_len(game_cls) -> int:
+    """the reference's HISTORY_LEN (config/basic.py:10): a ``HISTORY_LEN`` attribute of the class (alphazero_amd.games), else the
+    value the class's own module got from ``from config import *`` (every game module of the reference does that), else 8.
+    USE_HISTORY = False is refused: the reference's own no-history path does not run (training/self_play.py:59-70 concatenates a
+    2-D state with a 3-D player plane; core/MCTS_alphazero.py:208 does the opposite for 3-D states)."""
+    import sys
+
+    mod = sys.modules.get(getattr(game_cls, "__module__", ""), None)
+    if getattr(mod, "USE_HISTORY", True) is False:
+        raise EngineError("USE_HISTORY = False has no native path (and does not run in the reference either)")
+    h = getattr(game_cls, "HISTORY_LEN", None)
+    if h is None:
+        h = getattr(mod, "HISTORY_LEN", 8)
+    h = int(h)
+    if not 1 <= h <= 8:
+        raise EngineError("HISTORY_LEN 1 .. 8")
+    return h
+
+
 def engine_constants(game_cls) -> dict:
     """keyword arguments of ``Engine`` that carry a game class's constants beyond (game id, board size)"""
-    return {"win_length": resolve_win_length(game_cls), "board_cols": resolve_board_cols(game_cls)}
+    return {"win_length": resolve_win_length(game_cls), "board_cols": resolve_board_cols(game_cls),
+            "history_len": resolve_history_len(game_cls)}
 
 
 TaoSchedule = Union[float, Sequence[float], Callable[[int], float]]
@@ -299,6 +319,7 @@ class ChessArena:
         self.game_cls = game_cls
         self.game_id, self.board_size = resolve_game(game_cls)
         self.win_length, self.board_cols = resolve_win_length(game_cls), resolve_board_cols(game_cls)
+        self.history_len = resolve_history_len(game_cls)
         self.num_simulation, self.c_puct, self.epsilon, self.alpha = num_simulation, c_puct, epsilon, alpha
         self.n_slots, self.nn_dtype = n_slots, nn_dtype
         self.fused, self.use_graph = fused, use_graph
@@ -310,7 +331,8 @@ class ChessArena:
         if slots not in self._engines:
             self._engines[slots] = Engine(self.game_id, slots, self.num_simulation, board_size=self.board_size,
                                           c_puct=self.c_puct, epsilon=self.epsilon, nn_dtype=self.nn_dtype,
-                                          device=self.device, win_length=self.win_length, board_cols=self.board_cols)
+                                          device=self.device, win_length=self.win_length, board_cols=self.board_cols,
+                                          history_len=self.history_len)
         return self._engines[slots]
 
     # ---- reference surface -------------------------------------------------------------------

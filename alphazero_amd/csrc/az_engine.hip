@@ -75,6 +75,7 @@ struct View {  // kernel argument: raw device pointers + sizes
   int G, E, D;
   int K;        // leaves per tree per step (1 = the reference's sequential search); per-simulation arrays hold G*K rows
   int win;      // gomoku: stones in a row that win (WIN_LENGTH)
+  int hlen;     // HISTORY_LEN (config/basic.py:10): states in the dense NN input / the emitted samples, 1 .. 8
   float c_puct, epsilon;
   double vl;    // VIRTUAL_LOSS (config/basic.py:25), used by the wave kernels only
   int32_t *waveCnt;              // [G] leaves queued by the last k_select_wave
@@ -199,15 +200,16 @@ template <> __device__ __forceinline__ float cvt_in<f16_t>(f16_t v) {
 }
 
 // NN input of the position whose 8-state history ring is `hist` (oldest at index head):
-// core/MCTS_alphazero.py:202-209 + utils/history_manager.py:41-47 + games/base.py:116-121.
+// core/MCTS_alphazero.py:202-209 + utils/history_manager.py:41-47 + games/base.py:116-121.  hlen = the reference's HISTORY_LEN
+// (config/basic.py:10; 8 as shipped): the newest hlen states of the ring, oldest first, then the player plane.
 template <class GT, typename OutT>
-__device__ __forceinline__ void write_planes(const uint32_t (*hist)[GT::SW], int head, int player, OutT *out, int lane) {
-  constexpr int NIN = GT::CIN * GT::HW;
+__device__ __forceinline__ void write_planes(const uint32_t (*hist)[GT::SW], int head, int player, OutT *out, int lane, int hlen) {
+  const int cin = hlen * GT::CS + 1, NIN = cin * GT::HW;
   for (int idx = lane; idx < NIN; idx += 64) {
     const int c = idx / GT::HW, cell = idx % GT::HW;
     float v;
-    if (c == GT::CIN - 1) v = (float)player;
-    else v = GT::plane(hist[(head + c / GT::CS) & 7], c % GT::CS, cell);
+    if (c == cin - 1) v = (float)player;
+    else v = GT::plane(hist[(head + 8 - hlen + c / GT::CS) & 7], c % GT::CS, cell);
     out[idx] = cvt_out<OutT>(v);
   }
 }
@@ -443,7 +445,7 @@ __device__ __forceinline__ void select_gather_body(const View &v, OutT *nn_input
   if (kind == KIND_EVAL) {
     uint32_t *lr = v.leafRing + (size_t)g * 8 * GT::SW;
     for (int i = lane; i < 8 * GT::SW; i += 64) lr[i] = hist[(head + i / GT::SW) & 7][i % GT::SW];
-    if (nn_input) write_planes<GT, OutT>(hist, head, pl, nn_input + (size_t)g * (GT::CIN * GT::HW), lane);
+    if (nn_input) write_planes<GT, OutT>(hist, head, pl, nn_input + (size_t)g * ((v.hlen * GT::CS + 1) * GT::HW), lane, v.hlen);
   }
 }
 
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(64) void k_select_wave(View v, OutT *nn_input, int 
     if (kind == KIND_EVAL) {
       uint32_t *lr = v.leafRing + vs * 8 * GT::SW;
       for (int i = lane; i < 8 * GT::SW; i += 64) lr[i] = hist[(head + i / GT::SW) & 7][i % GT::SW];
-      if (nn_input) write_planes<GT, OutT>(hist, head, pl, nn_input + vs * (GT::CIN * GT::HW), lane);
+      if (nn_input) write_planes<GT, OutT>(hist, head, pl, nn_input + vs * ((v.hlen * GT::CS + 1) * GT::HW), lane, v.hlen);
       ++nEval;
     } else {
       ++nTerm;
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(64) void k_root_nn_state(View v, float *out) {
   const int ply = v.ply[g];
   load_ring<GT>(v.traj + (size_t)g * (GT::PMAX + 1) * GT::SW, ply, hist, lane);
   __syncthreads();
-  write_planes<GT, float>(hist, 0, v.player[g], out + (size_t)g * (GT::CIN * GT::HW), lane);
+  write_planes<GT, float>(hist, 0, v.player[g], out + (size_t)g * ((v.hlen * GT::CS + 1) * GT::HW), lane, v.hlen);
 }
 
 // ------------------------------------------------------------------------- play a move --------
@@ -1015,7 +1017,7 @@ __global__ __launch_bounds__(64) void k_emit_samples(View v, const int32_t *slot
   __syncthreads();
   const int8_t *tp = v.trajPlayer + (size_t)g * (GT::PMAX + 1);
   const int pl = tp[t];
-  write_planes<GT, float>(hist, 0, pl, states + row * (GT::CIN * GT::HW), lane);
+  write_planes<GT, float>(hist, 0, pl, states + row * ((v.hlen * GT::CS + 1) * GT::HW), lane, v.hlen);
   const uint16_t *tv = v.trajVisits + ((size_t)g * GT::PMAX + t) * A;
   int s = 0;
   for (int a = lane; a < A; a += 64) s += tv[a];
@@ -1040,10 +1042,11 @@ struct AugTables {
 
 template <class GT>
 __global__ __launch_bounds__(64) void k_augment(AugTables tb, const float *in_s, const float *in_p, const float *in_z,
-                                                float *out_s, float *out_p, float *out_z, long long cap, long long wr) {
+                                                float *out_s, float *out_p, float *out_z, long long cap, long long wr, int hlen) {
   const int i = blockIdx.x, t = blockIdx.y, lane = threadIdx.x, k = t >> 1;
   const bool flip = t & 1;
-  constexpr int A = GT::A, HW = GT::HW, NIN = GT::CIN * GT::HW, N = GT::H;
+  constexpr int A = GT::A, HW = GT::HW, N = GT::H;
+  const int CIN = hlen * GT::CS + 1, NIN = CIN * HW;
   long long row = wr + 8ll * i + t;
   if (cap > 0) row %= cap;
   const float *is = in_s + (size_t)i * NIN, *ip = in_p + (size_t)i * A;
@@ -1062,7 +1065,7 @@ __global__ __launch_bounds__(64) void k_augment(AugTables tb, const float *in_s,
     for (int idx = lane; idx < NIN; idx += 64) {
       const int c = idx / HW, cell = idx % HW, r = cell / WD, col = cell % WD;
       float v = 0.0f;
-      if (c == GT::CIN - 1) v = is[idx];
+      if (c == CIN - 1) v = is[idx];
       else {
         const int blk = c / 3, ch = c % 3;
         if (ch == 2) {
@@ -1236,7 +1239,8 @@ template <class GT>
 __global__ __launch_bounds__(64) void k_eval_hash_packed(View v, float scale, float *logits, float *values) {
   const int g = blockIdx.x, lane = threadIdx.x;
   if (!v.evalFlag[g]) return;  // terminal leaf / inactive slot: the row keeps its old contents, as with the dense batch
-  constexpr int NIN = GT::CIN * GT::HW, A = GT::A;
+  constexpr int A = GT::A;
+  const int cin = v.hlen * GT::CS + 1, NIN = cin * GT::HW, skip = 8 - v.hlen;
   __shared__ uint32_t ring[8][GT::SW];
   for (int i = lane; i < 8 * GT::SW; i += 64) ring[i / GT::SW][i % GT::SW] = v.leafRing[(size_t)g * 8 * GT::SW + i];
   const int player = v.leaf[g].w;
@@ -1244,7 +1248,7 @@ __global__ __launch_bounds__(64) void k_eval_hash_packed(View v, float scale, fl
   uint32_t h = 0;
   for (int i = lane; i < NIN; i += 64) {
     const int c = i / GT::HW, cell = i % GT::HW;
-    const float x = c == GT::CIN - 1 ? (float)player : GT::plane(ring[c / GT::CS], c % GT::CS, cell);
+    const float x = c == cin - 1 ? (float)player : GT::plane(ring[skip + c / GT::CS], c % GT::CS, cell);
     const uint32_t code = (uint32_t)((int)x + 1);
     h += mix32((uint32_t)i * 2654435761u + code * 40503u + 12345u);
   }
@@ -1328,7 +1332,7 @@ struct DeviceGuard {
 template <class GT>
 static void fill_dims(az_dims &d) {
   d.n_action = GT::A; d.state_channels = GT::CS; d.height = GT::H; d.width = GT::WD;
-  d.nn_channels = GT::CIN; d.max_plies = GT::PMAX; d.state_words = GT::SW;
+  d.nn_channels = GT::CIN; d.max_plies = GT::PMAX; d.state_words = GT::SW;  // (nn_channels: az_create rescales it by history_len)
 }
 
 static int launch_check(az_engine *e, const char *what) {
@@ -1349,6 +1353,8 @@ int az_create(const az_config *cfg, az_engine **out) {
   *out = nullptr;
   if (cfg->game < AZ_GAME_TICTACTOE || cfg->game > AZ_GAME_GOMOKU) { g_create_err = "unknown game"; return AZ_EINVAL; }
   const int win = cfg->win_length == 0 ? 5 : cfg->win_length;  // examples/gomoku/game.py:22
+  const int hlen = cfg->history_len == 0 ? 8 : cfg->history_len;  // config/basic.py:10 _HISTORY_LEN
+  if (hlen < 1 || hlen > 8) { g_create_err = "history_len (HISTORY_LEN, config/basic.py:10) 1 .. 8; 0 = the reference's 8"; return AZ_EINVAL; }
   // dots-and-boxes: board_size = BOX_ROWS (0 = the reference's 3), board_cols = BOX_COLS (0 = the same as the rows)
   const int dab_rows = cfg->board_size == 0 ? 3 : cfg->board_size, dab_cols = cfg->board_cols == 0 ? dab_rows : cfg->board_cols;
   if (cfg->game == AZ_GAME_DAB && (dab_rows < 2 || dab_rows > 5 || dab_cols < 2 || dab_cols > 5)) {
@@ -1369,10 +1375,12 @@ int az_create(const az_config *cfg, az_engine **out) {
   az_engine *e = new az_engine();
   e->cfg = *cfg;
   e->cfg.win_length = win;
+  e->cfg.history_len = hlen;
   if (cfg->game == AZ_GAME_DAB) { e->cfg.board_size = dab_rows; e->cfg.board_cols = dab_cols; }
   memset(&e->dims, 0, sizeof(e->dims));
   AZ_DISPATCH(e, fill_dims<GT>(e->dims));
   az_dims &d = e->dims;
+  d.nn_channels = hlen * d.state_channels + 1;  // HISTORY_LEN * C + 1: core/MCTS_alphazero.py:202-209
   const int A = d.n_action;
   d.n_slots = cfg->n_slots;
   d.node_cap = cfg->max_sims + 1;
@@ -1395,6 +1403,7 @@ int az_create(const az_config *cfg, az_engine **out) {
   v.G = d.n_slots; v.E = d.edge_cap; v.D = d.depth_cap;
   v.K = cfg->leaves_per_step > 1 ? cfg->leaves_per_step : 1;
   v.win = win;
+  v.hlen = hlen;
   v.vl = 0.3;  // VIRTUAL_LOSS, config/basic.py:25 (az_set_virtual_loss)
   d.leaves_per_step = v.K;
   v.c_puct = cfg->c_puct; v.epsilon = cfg->epsilon;
@@ -1508,11 +1517,12 @@ int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32
   if (root_player != 1 && root_player != -1) { e->err = "root_player must be +1 or -1"; return AZ_EINVAL; }
   const az_dims &d = e->dims;
   const int numel = d.state_channels * d.height * d.width, SW = d.state_words;
-  std::vector<uint32_t> words((size_t)8 * SW);
-  int nm[8];
-  for (int k = 0; k < 8; ++k) {
+  std::vector<uint32_t> words((size_t)8 * SW, 0u);
+  int nm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int first = 8 - e->v.hlen;  // history_host holds the newest HISTORY_LEN states (the reference's get_history()), oldest first
+  for (int k = first; k < 8; ++k) {
     bool ok = false;
-    AZ_DISPATCH(e, ok = GT::encode(history_host + (size_t)k * numel, words.data() + (size_t)k * SW, &nm[k]));
+    AZ_DISPATCH(e, ok = GT::encode(history_host + (size_t)(k - first) * numel, words.data() + (size_t)k * SW, &nm[k]));
     if (!ok) { e->err = "history holds a value outside {-1,0,1} or outside the board"; return AZ_EINVAL; }
   }
   const int ply = nm[7];
@@ -1523,13 +1533,13 @@ int az_set_position(az_engine *e, int32_t slot, const float *history_host, int32
     if (won) { e->err = "position is already terminal (a side has won)"; return AZ_EINVAL; }
   }
   // entries older than the start of the game must be the initial (empty) state
-  for (int k = 0; k < 8; ++k) {
+  for (int k = first; k < 8; ++k) {
     const int t = ply - 7 + k;
     if (t < 0 && nm[k] != 0) { e->err = "history is longer than the game (non-empty state before ply 0)"; return AZ_EINVAL; }
   }
   hipStream_t s = (hipStream_t)stream;
   uint32_t *tb = e->v.traj + (size_t)slot * (d.max_plies + 1) * SW;
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < 8; ++k) {  // (states older than the history the caller holds go in as empty boards: no output reads them)
     const int t = ply - 7 + k;
     if (t < 0) continue;
     AZ_HIP(hipMemcpyAsync(tb + (size_t)t * SW, words.data() + (size_t)k * SW, SW * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -1765,7 +1775,7 @@ int az_augment_samples(az_engine *e, int32_t n, const float *states_dev, const f
   static const AugTables tbs[4] = {make_aug_tables(2), make_aug_tables(3), make_aug_tables(4), make_aug_tables(5)};
   const AugTables &tb = tbs[e->cfg.game == AZ_GAME_DAB ? e->cfg.board_size - 2 : 1];
   AZ_DISPATCH(e, hipLaunchKernelGGL((k_augment<GT>), dim3(n, 8), dim3(64), 0, (hipStream_t)stream, tb, states_dev, pis_dev, z_dev,
-                                    out_states_dev, out_pis_dev, out_z_dev, (long long)ring_capacity, (long long)ring_write_idx));
+                                    out_states_dev, out_pis_dev, out_z_dev, (long long)ring_capacity, (long long)ring_write_idx, e->v.hlen));
   return launch_check(e, "k_augment");
 }
 

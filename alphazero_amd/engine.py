@@ -23,7 +23,8 @@ _NN_DTYPES = {torch.float32: NN_F32, torch.bfloat16: NN_BF16, torch.float16: NN_
 class AzConfig(C.Structure):
     _fields_ = [("game", C.c_int32), ("board_size", C.c_int32), ("n_slots", C.c_int32), ("max_sims", C.c_int32),
                 ("c_puct", C.c_float), ("epsilon", C.c_float), ("nn_dtype", C.c_int32), ("device", C.c_int32),
-                ("edge_cap", C.c_int32), ("leaves_per_step", C.c_int32), ("win_length", C.c_int32), ("board_cols", C.c_int32)]
+                ("edge_cap", C.c_int32), ("leaves_per_step", C.c_int32), ("win_length", C.c_int32), ("board_cols", C.c_int32),
+                ("history_len", C.c_int32)]
 
 
 class AzDims(C.Structure):
@@ -178,11 +179,13 @@ class Engine:
 
     def __init__(self, game: int, n_slots: int, max_sims: int, board_size: Optional[int] = None, c_puct: float = 1.0,
                  epsilon: float = 0.25, nn_dtype: torch.dtype = torch.float32, device=None, edge_cap: int = 0,
-                 leaves_per_step: int = 1, virtual_loss: float = 0.3, win_length: int = 5, board_cols: int = 0):
+                 leaves_per_step: int = 1, virtual_loss: float = 0.3, win_length: int = 5, board_cols: int = 0,
+                 history_len: int = 8):
         """leaves_per_step K > 1: virtual loss / in-tree leaf batching (select_wave / expand_wave); the per-simulation
         batch then has n_slots * K rows (``rows``).  Gomoku: board_size 3 .. 15 (default 15) and win_length 3 .. 6 are the
         reference's BOARD_SIZE / WIN_LENGTH constants (examples/gomoku/game.py:21-22).  Dots-and-boxes: board_size x board_cols =
-        BOX_ROWS x BOX_COLS (examples/dots_and_boxes/game.py:24-25), 2 .. 5 each; default 3 x 3, board_cols 0 = square."""
+        BOX_ROWS x BOX_COLS (examples/dots_and_boxes/game.py:24-25), 2 .. 5 each; default 3 x 3, board_cols 0 = square.
+        history_len = HISTORY_LEN (config/basic.py:10), 1 .. 8: states in the dense network input and the emitted samples."""
         if board_size is None or (game != GAME_GOMOKU and board_size > 5):  # (older callers passed the gomoku default for every game)
             board_size = 15 if game == GAME_GOMOKU else 3
         self.lib = load_library()
@@ -195,8 +198,8 @@ class Engine:
         self.device = torch.device("cuda", dev_index)
         self.nn_dtype = nn_dtype
         cfg = AzConfig(game, board_size, n_slots, max_sims, c_puct, epsilon, _NN_DTYPES[nn_dtype], dev_index,
-                       edge_cap, leaves_per_step, win_length, board_cols)
-        self.win_length = win_length
+                       edge_cap, leaves_per_step, win_length, board_cols, history_len)
+        self.win_length, self.history_len = win_length, history_len
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             rc = self.lib.az_create(C.byref(cfg), C.byref(h))
@@ -280,8 +283,8 @@ class Engine:
 
     def set_position(self, slot: int, history, root_player: int):
         h = torch.as_tensor(history, dtype=torch.float32, device="cpu").contiguous()
-        if h.numel() != 8 * self.dims.state_numel:
-            raise EngineError(f"history must hold 8 states of {self.dims.state_numel} values")
+        if h.numel() != self.history_len * self.dims.state_numel:
+            raise EngineError(f"history must hold {self.history_len} states of {self.dims.state_numel} values")
         self._ck(self.lib.az_set_position(self._h, slot, C.c_void_p(h.data_ptr()), int(root_player), self._stream()))
 
     def begin_search(self):

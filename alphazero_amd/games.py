@@ -26,6 +26,7 @@ HISTORY_LEN = 8
 
 class BaseGame:
     AZ_GAME: tuple  # (engine game id, board size)
+    HISTORY_LEN = HISTORY_LEN  # config/basic.py:10 (a module constant in the reference; per class here: with_history_len)
 
     def __init__(self) -> None:
         self.reset()
@@ -34,7 +35,7 @@ class BaseGame:
     def reset(self) -> None:
         self._state = self.initial_state()
         self._player = PLAYER1
-        self._history = deque([self.initial_state() for _ in range(HISTORY_LEN)], maxlen=HISTORY_LEN)
+        self._history = deque([self.initial_state() for _ in range(self.HISTORY_LEN)], maxlen=self.HISTORY_LEN)
 
     def step(self, action: int) -> bool:
         self._state, self._player = self.next_state(self._state, action, self._player)
@@ -48,7 +49,7 @@ class BaseGame:
         return self._state.detach().clone()
 
     def get_history(self) -> torch.Tensor:
-        """(8,H,W) for 2-D states, (8*C,H,W) for 3-D ones, oldest first (utils/history_manager.py:41-47)"""
+        """(HISTORY_LEN,H,W) for 2-D states, (HISTORY_LEN*C,H,W) for 3-D ones, oldest first (utils/history_manager.py:41-47)"""
         states = list(self._history)
         return (torch.stack(states, 0) if states[0].dim() == 2 else torch.cat(states, 0)).clone()
 
@@ -67,6 +68,15 @@ class BaseGame:
     @staticmethod
     def get_player_channel(state: torch.Tensor, player: int) -> torch.Tensor:
         return torch.full((1, *state.shape[-2:]), player)
+
+
+def with_history_len(game_cls, history_len: int):
+    """game_cls with the reference's HISTORY_LEN constant (config/basic.py:10) set to 1 .. 8: the engine then builds network
+    inputs and samples of history_len * C + 1 planes"""
+    h = int(history_len)
+    if not 1 <= h <= 8:
+        raise ValueError("with_history_len: 1 .. 8")
+    return game_cls if h == game_cls.HISTORY_LEN else type(f"{game_cls.__name__}H{h}", (game_cls,), {"HISTORY_LEN": h})
 
 
 class _StoneGame(BaseGame):

@@ -50,7 +50,7 @@ class MCTS:
             raise EngineError("MCTS.search needs a GPU (no CPU fallback)")
         eng = self._engine(num_simulation, c_puct, dev)
         d = eng.dims
-        hist = history_state.detach().to("cpu", torch.float32).reshape(8, -1)
+        hist = history_state.detach().to("cpu", torch.float32).reshape(eng.history_len, -1)
         if not torch.equal(hist[-1], root_state.detach().to("cpu", torch.float32).reshape(-1)):
             raise ValueError("the newest history entry must be root_state")
         eng.set_position(0, hist, int(root_player))

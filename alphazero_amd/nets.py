@@ -18,7 +18,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-HISTORY_LEN = 8  # config/basic.py:10
+HISTORY_LEN = 8  # config/basic.py:10 (the reference's models read it when they are built: the history_len arguments below)
 
 
 class DualHeadNet(nn.Module):
@@ -50,10 +50,10 @@ def _mlp_value(n_in: int) -> list[nn.Module]:
 class TicTacToeNet(DualHeadNet):
     """(B,9,3,3) -> (B,9),(B,1); 154,186 parameters."""
 
-    def __init__(self) -> None:
+    def __init__(self, history_len: int = HISTORY_LEN) -> None:
         super().__init__()
         c = 64
-        self._shared_layers = nn.Sequential(nn.Conv2d(HISTORY_LEN + 1, c, 3, padding=1), nn.ReLU(),
+        self._shared_layers = nn.Sequential(nn.Conv2d(history_len + 1, c, 3, padding=1), nn.ReLU(),
                                             nn.Conv2d(c, c, 3, padding=1), nn.ReLU())
         self._policy_head = nn.Sequential(nn.Flatten(1), nn.Linear(c * 9, 128), nn.ReLU(), nn.Linear(128, 9))
         self._value_head = nn.Sequential(nn.Flatten(1), *_mlp_value(c * 9))
@@ -63,12 +63,12 @@ class DotsAndBoxesNet(DualHeadNet):
     """(B,25,4,4) -> (B,24),(B,1); 53,532 parameters.  box_rows / box_cols: the reference's model reads its plane size and action
     count from the game class's constants (examples/dots_and_boxes/model.py:27-29, :44) -- the same network for another board."""
 
-    def __init__(self, box_rows: int = 3, box_cols: int = 0) -> None:
+    def __init__(self, box_rows: int = 3, box_cols: int = 0, history_len: int = HISTORY_LEN) -> None:
         super().__init__()
         r = int(box_rows)
         cc = int(box_cols) or r
         c, hw, n_action = 64, (r + 1) * (cc + 1), (r + 1) * cc + r * (cc + 1)
-        self._shared_layers = nn.Sequential(nn.Conv2d(HISTORY_LEN * 3 + 1, c, 3, padding=1), nn.ReLU(),
+        self._shared_layers = nn.Sequential(nn.Conv2d(history_len * 3 + 1, c, 3, padding=1), nn.ReLU(),
                                             nn.Conv2d(c, c, 3, padding=1), nn.ReLU())
         self._policy_head = nn.Sequential(nn.Conv2d(c, 2, 1), nn.ReLU(), nn.Flatten(1), nn.Linear(2 * hw, n_action))
         self._value_head = nn.Sequential(nn.Conv2d(c, 1, 1), nn.ReLU(), nn.Flatten(1), *_mlp_value(hw))
@@ -92,12 +92,12 @@ class _Res(nn.Module):
 class GomokuNet(DualHeadNet):
     """ResNet tower; defaults = the reference GomokuModel (15x15, 64 ch, 2 blocks, 233,257 params)."""
 
-    def __init__(self, board_size: int = 15, channels: int = 64, blocks: int = 2) -> None:
+    def __init__(self, board_size: int = 15, channels: int = 64, blocks: int = 2, history_len: int = HISTORY_LEN) -> None:
         super().__init__()
         a = board_size * board_size
         self.board_size = board_size
         self._shared_layers = nn.Sequential(
-            nn.Conv2d(HISTORY_LEN + 1, channels, 3, padding=1, bias=False), nn.BatchNorm2d(channels), nn.ReLU(),
+            nn.Conv2d(history_len + 1, channels, 3, padding=1, bias=False), nn.BatchNorm2d(channels), nn.ReLU(),
             *[_Res(channels) for _ in range(blocks)])
         self._policy_head = nn.Sequential(nn.Conv2d(channels, 1, 1, bias=False), nn.BatchNorm2d(1), nn.ReLU(),
                                           nn.Flatten(1), nn.Linear(a, a))

@@ -59,13 +59,17 @@ typedef struct az_config {
                           0 = the reference's 5; ignored otherwise */
   int32_t board_cols;  /* dots-and-boxes: BOX_COLS (examples/dots_and_boxes/game.py:25), 2 .. 5, 0 = the same as board_size;
                           ignored otherwise */
+  int32_t history_len; /* states in the network input = config/basic.py:10 _HISTORY_LEN, 1 .. 8; 0 = the reference's 8.  The
+                          dense batch, az_root_nn_state and the emitted samples then have history_len * C + 1 planes and
+                          az_set_position reads history_len states; the packed leaf batch always carries 8 states (the
+                          hand-written networks read it and exist for 8 only). */
 } az_config;
 
 typedef struct az_dims {
   int32_t n_action;       /* A */
   int32_t state_channels; /* channels of one state (1 for 2-D states) */
   int32_t height, width;
-  int32_t nn_channels;    /* C_in = 8 * state_channels + 1 (USE_HISTORY, HISTORY_LEN = 8) */
+  int32_t nn_channels;    /* C_in = history_len * state_channels + 1 (USE_HISTORY; HISTORY_LEN = 8 as shipped) */
   int32_t max_plies;
   int32_t state_words;    /* u32 words of one bitboard state */
   int32_t edge_cap, node_cap, depth_cap;
@@ -97,7 +101,7 @@ int az_check(az_engine *e, void *stream);      /* synchronises; AZ_EDEVICE if a 
 int az_reset_games(az_engine *e, const uint8_t *mask_dev, void *stream);
 
 /* Load an arbitrary position into one slot (the MCTS.search(root_state, root_player,
- * history_state) arguments, core/MCTS_alphazero.py:128-137).  history_host: 8 states of
+ * history_state) arguments, core/MCTS_alphazero.py:128-137).  history_host: history_len (8) states of
  * state_channels*height*width f32 each, oldest first, newest == root state (utils/history_manager.py:41-47).
  * Host pointer; synchronous.  A root that is already decided (a side has won, or no move is left) is refused with
  * AZ_EINVAL: the reference evaluates such a node by rule (:157-158), there is nothing to search.  The slot gets a

@@ -73,7 +73,7 @@ def dab_box_perm(k, flip, B=3):
 
 
 def augment_dab(state, pi, z):
-    """state (25,D,D), pi (2 B D,) (game.py:158-259)"""
+    """state (3 HISTORY_LEN + 1,D,D), pi (2 B D,) (game.py:158-259)"""
     B = state.shape[-1] - 1
     if state.shape[-2] != state.shape[-1]:
         raise ValueError("the dots-and-boxes symmetries need a square board (game.py:318-319)")
@@ -83,7 +83,7 @@ def augment_dab(state, pi, z):
         for flip in (False, True):
             ep, bp = dab_edge_perm(k, flip, B), dab_box_perm(k, flip, B)
             o = np.zeros_like(state)
-            for blk in range(8):
+            for blk in range((state.shape[0] - 1) // 3):  # HISTORY_LEN blocks of 3 planes (game.py:182-203)
                 base = 3 * blk
                 for a in range(A):
                     t, r, c = _a2e(a, B)

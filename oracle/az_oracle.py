@@ -90,6 +90,24 @@ class box_shape:
         return False
 
 
+class history_len:
+    """``with history_len(h):`` the oracle runs with the reference's HISTORY_LEN constant (config/basic.py:10) set to h (1 .. 8) --
+    process-wide, restored on exit."""
+
+    def __init__(self, h: int):
+        self.h, self.old = int(h), None
+
+    def __enter__(self):
+        if not 1 <= self.h <= 8:
+            raise ValueError("HISTORY_LEN 1 .. 8")
+        self.old = lib().az_oracle_set_history_len(self.h)
+        return self
+
+    def __exit__(self, *exc):
+        lib().az_oracle_set_history_len(self.old)
+        return False
+
+
 def dims(game: int, board_size: int = 15) -> dict:
     out = (C.c_int * 6)()
     if lib().az_oracle_dims(game, board_size, out) != 0:
@@ -139,7 +157,7 @@ def search(game, board_size, root_state, root_player, history, num_sim, eval_fn,
     A = d["A"]
     root_state = np.ascontiguousarray(root_state, np.float32).reshape(-1)
     history = np.ascontiguousarray(history, np.float32).reshape(-1)
-    assert root_state.size == d["numel"] and history.size == 8 * d["numel"]
+    assert root_state.size == d["numel"] and history.size == (d["cin"] - 1) * d["H"] * d["W"]
     noise = None if noise is None else np.ascontiguousarray(noise, np.float32).reshape(-1)
     po = None if prior_override is None else np.ascontiguousarray(prior_override, np.float32)
     pi = np.zeros(A, np.float32)

@@ -60,6 +60,12 @@ def box_of(tag):
     return (int(m.group(1)), int(m.group(2))) if m else (3, 3)
 
 
+def hist_of(tag):
+    """fixture tag -> the reference's HISTORY_LEN the fixture was recorded under ("dab_h2_0" -> 2; 8 where the tag does not say)"""
+    m = re.search(r"_h(\d)(_|$)", tag)
+    return int(m.group(1)) if m else 8
+
+
 def cols_of(tag):
     """the board_cols argument of Engine for a fixture tag (BOX_COLS of a dots-and-boxes fixture, 0 otherwise)"""
     return box_of(tag)[1] if tag.startswith("dab") else 0
@@ -67,10 +73,10 @@ def cols_of(tag):
 
 class reference_constants:
     """``with reference_constants(oracle, tag):`` the oracle under the constants the reference had when the fixture was recorded:
-    WIN_LENGTH of gomoku<N>k<K>, BOX_ROWS x BOX_COLS of dab<R>x<C>"""
+    WIN_LENGTH of gomoku<N>k<K>, BOX_ROWS x BOX_COLS of dab<R>x<C>, HISTORY_LEN of <game>_h<H>"""
 
     def __init__(self, oracle, tag):
-        self.cm = [oracle.win_length(win_of(tag)), oracle.box_shape(*box_of(tag))]
+        self.cm = [oracle.win_length(win_of(tag)), oracle.box_shape(*box_of(tag)), oracle.history_len(hist_of(tag))]
 
     def __enter__(self):
         for c in self.cm:

@@ -831,6 +831,77 @@ def make_dab_shapes():
         set_box_shape(3, 3)
 
 
+def set_history_len(h):
+    """the reference's HISTORY_LEN (config/basic.py:10 _HISTORY_LEN -> :39-40): every module that did ``from config import *``
+    holds its own binding, all read at call time (utils/history_manager.py:21,38,52; the models' __init__)"""
+    for mod in list(sys.modules.values()):
+        if mod is not None and "HISTORY_LEN" in getattr(mod, "__dict__", {}) and getattr(mod, "__name__", "") != __name__:
+            mod.HISTORY_LEN = h
+
+
+class GomokuHModel(BaseModel):
+    """GomokuNModel with the input planes of a given HISTORY_LEN"""
+
+    def __init__(self, n, h):
+        super().__init__()
+        self._s = torch.nn.Sequential(torch.nn.Conv2d(h + 1, 8, 3, padding=1), torch.nn.ReLU())
+        self._p = torch.nn.Sequential(torch.nn.Flatten(1), torch.nn.Linear(8 * n * n, n * n))
+        self._v = torch.nn.Sequential(torch.nn.Flatten(1), torch.nn.Linear(8 * n * n, 1), torch.nn.Tanh())
+
+    @property
+    def shared_layers(self):
+        return self._s
+
+    def policy_head(self, x):
+        return self._p(x)
+
+    def value_head(self, x):
+        return self._v(x)
+
+
+def make_history():
+    """the reference's own MCTS / ChessArena / models with HISTORY_LEN changed: searches and self-play games whose network inputs
+    and samples have HISTORY_LEN * C + 1 planes.  Tags carry the value: <game>_h<HISTORY_LEN>_<i>."""
+    try:
+        rng = np.random.default_rng(13)
+        cases = []
+        for j, (h, game_cls, mk, tag, specs) in enumerate([
+                (3, TicTacToeGame, lambda: TicTacToeModel(), "tictactoe", [(0, 50, True), (4, 80, True), (6, 50, False)]),
+                (1, DotsAndBoxesGame, lambda: DotsAndBoxesModel(), "dab", [(0, 80, True), (15, 80, True), (20, 120, False)]),
+                (5, GomokuGame, lambda: GomokuHModel(9, 5), "gomoku9", [(0, 80, True), (12, 100, True), (30, 60, False)]),
+                (2, GomokuGame, lambda: GomokuModel(), "gomoku15", [(6, 40, True)])]):
+            set_history_len(h)
+            GomokuGame.BOARD_SIZE = 9 if tag == "gomoku9" else 15
+            torch.manual_seed(740 + j)
+            model = mk().eval()
+            for i, (nm, ns, ud) in enumerate(specs):
+                c = search_case(game_cls, model, nm, ns, ud, rng, 950 + 10 * j + i)
+                assert c["history"].size == h * c["root_state"].size
+                cases.append((f"{tag}_h{h}_{i}", c))
+                print("search", cases[-1][0], "moves", nm, "sims", ns, "input", c["eval_in"].shape)
+        out = {"tags": np.array([t for t, _ in cases])}
+        for t, c in cases:
+            for kk, v in c.items():
+                out[f"{t}__{kk}"] = v
+        np.savez_compressed(os.path.join(OUT, "search_hist.npz"), **out)
+
+        cases = []
+        for h, game_cls, model_cls, tag, sims, tao, seed in ((3, TicTacToeGame, TicTacToeModel, "tictactoe", 40, 1.0, 41),
+                                                           (2, DotsAndBoxesGame, DotsAndBoxesModel, "dab", 30, 0.8, 42),
+                                                           (1, TicTacToeGame, TicTacToeModel, "tictactoe", 40, 1.0, 43)):
+            set_history_len(h)
+            cases.append((f"{tag}_h{h}_0", dedup_evals(selfplay_case(game_cls, model_cls, sims, tao, seed, 750 + h))))
+        out = {"tags": np.array([t for t, _ in cases])}
+        for t, c in cases:
+            print("selfplay", t, "plies", int(c["plies"]), "evals", len(c["eval_in"]), "state", c["state_shape"])
+            for kk, v in c.items():
+                out[f"{t}__{kk}"] = v
+        np.savez_compressed(os.path.join(OUT, "selfplay_hist.npz"), **out)
+    finally:
+        set_history_len(8)
+        GomokuGame.BOARD_SIZE = 15
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rules", "search", "selfplay", "augment", "loss", "quick"]
     if "quick" in which:
@@ -853,3 +924,5 @@ if __name__ == "__main__":
         make_mnk()
     if "dabshapes" in which:  # dots-and-boxes under other BOX_ROWS / BOX_COLS constants
         make_dab_shapes()
+    if "history" in which:  # other values of HISTORY_LEN
+        make_history()

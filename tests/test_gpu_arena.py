@@ -2,6 +2,7 @@
 (core/MCTS_alphazero.py:128) served by the HIP engine, against the CPU oracle driven with the same
 seeded randomness and the same (integer-exact) network."""
 import functools
+import sys
 
 import numpy as np
 import pytest
@@ -139,6 +140,59 @@ def test_arena_on_a_dots_and_boxes_class_with_other_constants(oracle, rows, cols
     assert (w is None) == (r["result"] == 0.0)
     # the single-position adapter with the mirror network sized from the constants
     net = nets.DotsAndBoxesNet(rows, cols).cuda().eval()
+    g = cls()
+    g.step(1)
+    pi = MCTS(cls).search(net, g.get_state(), g.get_player(), history_state=g.get_history(), num_simulation=20, use_Dirichlet=False)
+    assert pi.shape == (1, A) and abs(float(pi.sum()) - 1.0) < 1e-5 and float(pi[0, 1]) == 0.0
+
+
+@pytest.mark.parametrize("name,h", [("tictactoe", 3), ("dab", 1), ("gomoku9", 4)])
+def test_arena_with_another_history_length(oracle, name, h):
+    """the reference's HISTORY_LEN constant (config/basic.py:10) at another value: ChessArena reads it from the game class (the
+    mirror's attribute; for the reference's own classes, the binding their module got from ``from config import *``), the samples
+    have h * C + 1 planes and replay on the oracle under the same constant; the mirror networks take the same argument"""
+    import types
+
+    from alphazero_amd import games, nets
+    from alphazero_amd.arena import ChessArena, resolve_history_len
+    from alphazero_amd.mcts import MCTS
+
+    base = _game_cls(name)
+    cls = games.with_history_len(base, h)
+    game, n = cls.AZ_GAME
+    assert cls.HISTORY_LEN == h and cls().get_history().shape[0] == h * (3 if name == "dab" else 1)
+    # a class of the reference's has no such attribute: its module's HISTORY_LEN is what counts
+    mod = types.ModuleType("fake_reference_game_module")
+    mod.HISTORY_LEN, mod.USE_HISTORY = h, True
+    sys.modules[mod.__name__] = mod
+    try:
+        ref_like = type("GomokuGame", (), {"__module__": mod.__name__, "BOARD_SIZE": 9})
+        assert resolve_history_len(ref_like) == h
+        mod.USE_HISTORY = False
+        with pytest.raises(Exception, match="USE_HISTORY"):
+            resolve_history_len(ref_like)
+    finally:
+        del sys.modules[mod.__name__]
+    with oracle.history_len(h):
+        d = oracle.dims(game, n)
+        A, sims, seed = d["A"], 25, 79
+        P = min(A, 30)
+        noise, expo = _reference_draws(seed, A, P)
+        arena = ChessArena(functools.partial(HashNet, A, 5.0), cls, torch.device("cuda:0"), num_simulation=sims)
+        assert arena.history_len == h
+        pool = ListPool()
+        torch.manual_seed(seed)
+        if name != "gomoku9":  # (a 25-simulation gomoku game outlasts the recorded draws)
+            arena.self_play(1.0, pool)
+            ev = oracle.torch_eval(HashNet(A, 5.0), (d["cin"], d["H"], d["W"]))
+            r = oracle.self_play(game, n, sims, 1.0, expo, ev, noise=noise, max_plies=P)
+            assert len(pool.items) == r["plies"]
+            for j, (st, pi, z) in enumerate(pool.items):
+                t = r["plies"] - 1 - j
+                assert st.shape == (1, d["cin"], d["H"], d["W"]) and np.array_equal(st.numpy().reshape(-1), r["nn_states"][t])
+                assert np.array_equal(pi.numpy().reshape(-1), r["pis"][t]) and float(z[0]) == float(r["z"][t])
+    net = {"tictactoe": lambda: nets.TicTacToeNet(history_len=h), "dab": lambda: nets.DotsAndBoxesNet(history_len=h),
+           "gomoku9": lambda: nets.GomokuNet(9, history_len=h)}[name]().cuda().eval()
     g = cls()
     g.step(1)
     pi = MCTS(cls).search(net, g.get_state(), g.get_player(), history_state=g.get_history(), num_simulation=20, use_Dirichlet=False)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from .conftest import DAB_SHAPES, cols_of, game_of, load_cases, reference_constants, win_of
+from .conftest import DAB_SHAPES, cols_of, game_of, hist_of, load_cases, win_of
 
 pytestmark = pytest.mark.gpu
 
@@ -197,6 +197,77 @@ def test_other_box_shapes_match_oracle(oracle, rows, cols):
                     assert np.array_equal(os_[8 * i + t], ws[t].reshape(-1)) and np.array_equal(op[8 * i + t], wp[t])
 
 
+@pytest.mark.parametrize("name,game,n,h", [("tictactoe", 0, 3, 1), ("tictactoe", 0, 3, 4), ("dab", 1, 3, 2), ("dab", 1, 3, 7), ("gomoku9", 2, 9, 3),
+                                           ("gomoku15", 2, 15, 6)])
+def test_other_history_lengths_match_oracle(oracle, name, game, n, h):
+    """the reference's HISTORY_LEN constant at other values (config/basic.py:10): the dense network input, the hash evaluator on
+    the packed batch, az_root_nn_state, whole self-play games with their emitted samples and the 8 symmetries all have
+    h * C + 1 planes and equal the oracle running with the same constant"""
+    from oracle import augment as AUG
+
+    rng = np.random.default_rng(6000 + 10 * game + h)
+    G, sims = 12, 60
+    with oracle.history_len(h):
+        d = oracle.dims(game, n)
+        A, C = d["A"], d["C"]
+        assert d["cin"] == h * C + 1
+        eng = _engine(game, n, G, sims, history_len=h)
+        assert eng.dims.nn_channels == h * C + 1 and eng.dims.nn_numel == (h * C + 1) * d["H"] * d["W"]
+        pos = [_random_position(oracle, game, n, int(rng.integers(0, {0: 6, 1: 20, 2: 30}[game] + 1)), rng) for _ in range(G)]
+        for g, (hist, p) in enumerate(pos):
+            eng.set_position(g, hist[8 - h:], p)  # the newest h states: what the reference's get_history() returns
+        got = eng.root_nn_state().cpu().numpy().reshape(G, h * C + 1, -1)
+        for g, (hist, p) in enumerate(pos):
+            assert np.array_equal(got[g, :-1].reshape(-1), hist[8 - h:].reshape(-1)) and np.all(got[g, -1] == p)
+        noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
+        noise = torch.from_numpy(noise_np).cuda()
+        pi, visits, q, prior = _run_search(eng, sims, lambda x, l, v: eng.eval_hash(x, l, v, 6.0), noise)
+        fn, ctx, _keep = oracle.hash_eval(6.0)
+        for g, (hist, p) in enumerate(pos):
+            r = oracle.search(game, n, hist[-1], p, hist[8 - h:], sims, fn, ctx, noise=noise_np[g])
+            assert np.array_equal(visits[g], r["visits"]) and np.array_equal(pi[g], r["pi"]), (name, h, g)
+            assert np.array_equal(q[g], r["child_q"]) and np.array_equal(prior[g], r["root_prior"]), (name, h, g)
+        # the same search with the evaluator reading the packed batch (no dense input written at all)
+        for g, (hist, p) in enumerate(pos):
+            eng.set_position(g, hist[8 - h:], p)
+        logits, values = eng.new(G, A), eng.new(G)
+        eng.begin_search()
+        for _ in range(sims):
+            eng.select_gather(None)
+            eng.eval_hash(None, logits, values, 6.0)  # NULL input: the evaluator reads the packed batch
+            eng.expand_backup(logits, values, noise)
+        v2 = eng.new(G, A, dtype=torch.int32)
+        eng.root_policy(visits=v2)
+        eng.check()
+        assert np.array_equal(v2.cpu().numpy(), visits)
+        # whole games, their samples, the symmetries
+        P = {0: 9, 1: 24, 2: 40}[game]
+        eng = _engine(game, n, 6, 20, history_len=h)
+        noise_tab = rng.dirichlet([0.3] * A, size=(6, P)).astype(np.float32)
+        expo_tab = rng.exponential(1.0, size=(6, P, A)).astype(np.float32)
+        if game == 2:  # (a 20-simulation gomoku game rarely ends within 40 plies: compare the first plies' moves only)
+            return
+        acts, plies = _self_play(eng, 20, lambda x, l, v: eng.eval_hash(x, l, v, 5.0), noise_tab, expo_tab, 1.0)
+        slots = sorted(plies)
+        states, pis, z, offs = eng.emit_samples(slots, [plies[g] for g in slots])
+        states_np, pis_np, z_np = states.cpu().numpy(), pis.cpu().numpy(), z.cpu().numpy()
+        fn, ctx, _keep = oracle.hash_eval(5.0)
+        for i, g in enumerate(slots):
+            r = oracle.self_play(game, n, 20, 1.0, expo_tab[g], fn, ctx, noise=noise_tab[g], max_plies=P)
+            assert r["plies"] == plies[g] and list(r["actions"]) == acts[g], (name, h, g)
+            lo, hi = int(offs[i]), int(offs[i + 1])
+            assert states_np.shape[1] == (h * C + 1) * d["H"] * d["W"]
+            assert np.array_equal(states_np[lo:hi], r["nn_states"][::-1]) and np.array_equal(pis_np[lo:hi], r["pis"][::-1])
+            assert np.array_equal(z_np[lo:hi], r["z"][::-1])
+        k = min(5, states_np.shape[0])
+        os_, op, oz = eng.augment_samples(states[:k].contiguous(), pis[:k].contiguous(), z[:k].contiguous())
+        os_, op = os_.cpu().numpy(), op.cpu().numpy()
+        for i in range(k):
+            ws, wp, _ = AUG.augment(game, states_np[i].reshape(h * C + 1, d["H"], d["W"]), pis_np[i], z_np[i])
+            for t in range(8):
+                assert np.array_equal(os_[8 * i + t], ws[t].reshape(-1)) and np.array_equal(op[8 * i + t], wp[t]), (name, h, i, t)
+
+
 @pytest.mark.parametrize("name,game,n,sims,moves", [("gomoku15", 2, 15, 220, 0), ("gomoku15", 2, 15, 150, 40), ("gomoku9", 2, 9, 120, 3)])
 def test_deep_narrow_trees_match_oracle(oracle, name, game, n, sims, moves):
     """One-line searches: paths far longer than a wavefront is wide (the backup's second loop), a terminal leaf at the
@@ -251,17 +322,18 @@ def test_all_legal_priors_underflow_is_an_error_like_the_reference():
         eng.check()
 
 
-SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz"), **load_cases("search_dab.npz")}
+SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz"), **load_cases("search_dab.npz"), **load_cases("search_hist.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SEARCH))
 def test_search_matches_reference_golden(oracle, tag):
     """The reference's own recorded searches; the network is replayed from the recorded table.  (gomoku<N>k<K>: recorded with
-    the reference's BOARD_SIZE / WIN_LENGTH constants set to N / K; dab<R>x<C>: with its BOX_ROWS / BOX_COLS set to R / C.)"""
+    the reference's BOARD_SIZE / WIN_LENGTH constants set to N / K; dab<R>x<C>: with its BOX_ROWS / BOX_COLS set to R / C;
+    <game>_h<H>: with HISTORY_LEN = H, the recorded network inputs then have H * C + 1 planes.)"""
     c = SEARCH[tag]
     game, n = game_of(tag)
     sims = int(c["num_sim"])
-    eng = _engine(game, n, 1, sims, win_length=win_of(tag), board_cols=cols_of(tag))
+    eng = _engine(game, n, 1, sims, win_length=win_of(tag), board_cols=cols_of(tag), history_len=hist_of(tag))
     d = eng.dims
     eng.set_position(0, c["history"].astype(np.float32), int(c["root_player"]))
     table = {c["eval_in"][i].astype(np.float32).tobytes(): (c["eval_logits"][i], c["eval_value"][i])
@@ -344,7 +416,7 @@ def test_self_play_matches_oracle_hash_net(oracle, name, game, n, sims, tao):
         assert result[g] == r["result"]
 
 
-SELFPLAY = {**load_cases("selfplay.npz"), **load_cases("selfplay_dab.npz")}
+SELFPLAY = {**load_cases("selfplay.npz"), **load_cases("selfplay_dab.npz"), **load_cases("selfplay_hist.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SELFPLAY))
@@ -352,7 +424,7 @@ def test_self_play_matches_reference_golden(oracle, tag):
     c = SELFPLAY[tag]
     game, n = game_of(tag)
     sims, tao = int(c["num_sim"]), float(c["tao"])
-    eng = _engine(game, n, 1, sims, board_cols=cols_of(tag))
+    eng = _engine(game, n, 1, sims, board_cols=cols_of(tag), history_len=hist_of(tag))
     table = {c["eval_in"][i].astype(np.float32).tobytes(): (c["eval_logits"][i], c["eval_value"][i])
              for i in range(len(c["eval_in"]))}
 

@@ -60,7 +60,7 @@ def _table(c):
             for i in range(len(c["eval_in"]))}
 
 
-SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz"), **load_cases("search_dab.npz")}
+SEARCH = {**load_cases("search.npz"), **load_cases("search_mnk.npz"), **load_cases("search_dab.npz"), **load_cases("search_hist.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SEARCH))
@@ -100,7 +100,7 @@ def test_search_kat_reference_priors(oracle, tag):
     assert np.array_equal(r["root_prior"], c["root_prior"])
 
 
-SELFPLAY = {**load_cases("selfplay.npz"), **load_cases("selfplay_dab.npz")}
+SELFPLAY = {**load_cases("selfplay.npz"), **load_cases("selfplay_dab.npz"), **load_cases("selfplay_hist.npz")}
 
 
 @pytest.mark.parametrize("tag", sorted(SELFPLAY))
