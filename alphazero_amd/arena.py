@@ -286,6 +286,15 @@ class SelfPlayRunner:
                 break
             steps(max((left + K - 1) // K, 4))
 
+    def check(self) -> None:
+        """the engine's device error flag (Engine.check) and, for the f16 towers, the overflow flag: an activation beyond f16's
+        range means every evaluation since is wrong -- raised, never ignored (use the f32 or bf16 tower for such a network).
+        Synchronises; call it where the reference would have seen the exception: at the end of a batch of moves."""
+        self.e.check()
+        if self.fused is not None and getattr(self.fused, "overflowed", lambda: False)():
+            raise EngineError(f"the {self.fused.precision} tower overflowed f16's range (an activation above 4,094): its results are "
+                              "invalid for this network -- use fused='f32' or 'bf16r'")
+
     def move_round(self, inv_tao: torch.Tensor, forced: Optional[torch.Tensor] = None):
         """search + temperature sampling + step, for every active slot (training/self_play.py:36-83)"""
         self.search()
@@ -444,6 +453,6 @@ class ChessArena:
                 inv_tao.copy_(inv_tao_h)
                 run.game_ids.copy_(ids_h)
                 eng.reset_games(restart.to(eng.device))
-        eng.check()
+        run.check()
         self.games_played += n_games
         return {"games": n_games, "samples": samples}

@@ -544,6 +544,9 @@ class SmallNetEvaluator:
     def supports(cls, model: nn.Module) -> bool:
         return cls.game_of(model) is not None
 
+    def overflowed(self) -> bool:
+        return False  # (f32 arithmetic: the FusedTowerEvaluator interface)
+
     def __init__(self, model: nn.Module):
         self.game = self.game_of(model)
         if self.game is None:

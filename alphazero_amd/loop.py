@@ -114,6 +114,6 @@ class SelfPlayTrainLoop:
     def run(self, n_moves: int) -> dict:
         for _ in range(n_moves):
             self.move()
-        self.engine.check()
+        self.runner.check() if hasattr(self.runner, "check") else self.engine.check()
         return {"moves": self.moves, "games": self.games_finished, "samples": self.samples,
                 "train_steps": self.train_steps, "loss": self.last_loss}

@@ -203,6 +203,10 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
         class _PackedOnly:  # (makes the runner pass nn_input = NULL: no dense planes are written)
             kernel_events, generation = None, 0
 
+            @staticmethod
+            def overflowed():
+                return False
+
         run.fused = _PackedOnly()
         run.evaluate = lambda: eng.eval_hash(None, run.logits, run.values, args.hash_scale)
     wave = eng.leaves_per_step > 1  # virtual loss / in-tree leaf batching: several leaves per tree per network batch
@@ -274,7 +278,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
             run.game_ids += again.to(torch.int64) * (world * slots)  # a restarted slot is a new game: a fresh id of this rank's residue class
             ids_started += slots  # (ids below rank + world * ids_started are taken)
         run.num_sims = sims
-        eng.check()
+        run.check()  # the engine's error flag + an f16 tower's overflow flag
 
     ev_tree, ev_nn, ev_tower = [], [], []
     EVENT_EVERY = 8  # every 8th simulation step of the timed region is bracketed with HIP events
@@ -322,7 +326,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     for _ in range(warmup):
         step(False)
     finalize_pending()
-    eng.check()
+    run.check()  # the engine's error flag + an f16 tower's overflow flag
     eng.reset_stats()
     finished_games = finished_plies = 0
     torch.cuda.synchronize()
@@ -338,7 +342,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
         dst.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    eng.check()
+    run.check()  # the engine's error flag + an f16 tower's overflow flag
     st = eng.read_stats()
     if args.graph and not wave:  # kernel times: one eager, event-bracketed probe step outside the timed region
         eng.reset_stats()
@@ -599,7 +603,7 @@ def decision_agreement(args, dev, n_pos=1024, plies=12, other="bf16"):
         run.search()
         visits = eng.new(n_pos, A, dtype=torch.int32)
         pi = eng.root_policy(visits=visits)
-        eng.check()
+        run.check()  # the engine's error flag + an f16 tower's overflow flag
         _, _, active, _ = eng.game_info()
         res[name] = (visits.clone(), (pi / expo).argmax(1), active.bool().clone())
         del run

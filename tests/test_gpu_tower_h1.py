@@ -144,6 +144,20 @@ def test_row_tile_tower_limits_and_overflow_flag():
     x = torch.randint(-1, 2, (8, 9, 15, 15), device="cuda").float()
     ev(x.contiguous())
     assert ev.overflowed()
+    # ... and a self-play run on such a network fails loudly instead of playing on garbage (SelfPlayRunner.check)
+    from alphazero_amd import Engine
+    from alphazero_amd.arena import SelfPlayRunner
+
+    eng = Engine(2, 16, 4, board_size=15, device="cuda:0")
+    run = SelfPlayRunner(eng, net, 4, fused="f16", seed=1)
+    run.move_round(torch.ones(16, device="cuda"))
+    with pytest.raises(EngineError, match="overflowed"):
+        run.check()
+    ok = SelfPlayRunner(eng, net, 4, fused="f32", seed=1)  # the f32 tower takes the same network
+    eng.reset_games()
+    ok.move_round(torch.ones(16, device="cuda"))
+    ok.check()
+    eng.close()
     for prec in ("f16", "bf16r"):
         with pytest.raises(EngineError):
             FusedTowerEvaluator(GomokuNet(9, 64, 1).eval().cuda(), prec)  # 15x15 only
