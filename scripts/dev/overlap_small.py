@@ -18,7 +18,8 @@ def run(parts, moves=6):
     ers = []
     for _ in range(parts):
         eng = Engine(game, slots, sims, board_size=n, nn_dtype=torch.float32, device=dev)
-        ers.append((eng, SelfPlayRunner(eng, model, sims, fused=True, use_graph=True, graph_unit=1)  # one step per graph: move() replays sims - 1 times))
+        # one step per graph: move() replays sims - 1 times
+        ers.append((eng, SelfPlayRunner(eng, model, sims, fused=True, use_graph=True, graph_unit=1)))
     streams = [torch.cuda.Stream(dev) for _ in range(parts)]
     it = [torch.ones(slots, device=dev) for _ in range(parts)]
 
