@@ -43,6 +43,38 @@ def test_row_tile_tower_matches_fp32_forward(precision, blocks, batch):
     assert torch.equal(p2, p[perm]) and torch.equal(v2, v[perm])
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16", "bf16r", "f16", "f16x2"])
+def test_every_tower_at_the_bench_batch_is_a_function_of_the_board_alone(precision):
+    """BASELINE's full size (16,384 boards per launch, the reference GomokuModel): size-independent properties of every
+    hand-written tower -- a board's row does not depend on where in the batch it stands or on what else is in the batch
+    (a reversed batch and a 300-board slice give the same rows bit for bit), and stays within its precision's bar of the fp32
+    forward on a sample of the rows"""
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    torch.manual_seed(5)
+    G = 16384
+    net = _randomised(GomokuNet(15, 64, 2)).eval().cuda()
+    ev = FusedTowerEvaluator(net, precision)
+    dt = ev.in_dtype
+    x = torch.randint(-1, 2, (G, 9, 15, 15), device="cuda").float()
+    x[:, 8] = torch.where(torch.rand(G, 1, 1, device="cuda") < 0.5, -1.0, 1.0)
+    p, v = ev(x.to(dt).contiguous())
+    p, v = p.clone(), v.clone()
+    assert not ev.overflowed() and bool(torch.isfinite(p).all()) and bool((v.abs() <= 1).all())
+    p2, v2 = ev(x.flip(0).to(dt).contiguous())
+    assert torch.equal(p2.flip(0), p) and torch.equal(v2.flip(0), v)
+    lo = 7001
+    p3, v3 = ev(x[lo:lo + 300].to(dt).contiguous())
+    assert torch.equal(p3, p[lo:lo + 300]) and torch.equal(v3, v[lo:lo + 300])
+    with torch.inference_mode():
+        ref_p, ref_v = net(x[:512])
+    scale = float(ref_p.abs().max())
+    bar = {"f32": 2e-4, "f16x2": 2e-4, "f16": 0.004, "bf16": 0.03, "bf16r": 0.03}[precision]
+    assert float((p[:512] - ref_p).abs().max()) <= bar * scale + bar
+    assert float((v[:512] - ref_v).abs().max()) <= bar + 1e-4
+
+
 def test_f16_is_several_times_closer_to_f32_than_bf16():
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import GomokuNet
