@@ -7,7 +7,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(_HERE, "csrc", "az_engine.hip"), os.path.join(_HERE, "csrc", "az_tower.hip"),
         os.path.join(_HERE, "csrc", "az_tower_f32.hip"), os.path.join(_HERE, "csrc", "az_smallnet.hip"),
-        os.path.join(_HERE, "csrc", "az_tower_h2.hip"), os.path.join(_HERE, "csrc", "az_tower_h1.hip")]
+        os.path.join(_HERE, "csrc", "az_tower_h2.hip"), os.path.join(_HERE, "csrc", "az_tower_h1.hip"),
+        os.path.join(_HERE, "csrc", "az_tower_w.hip")]
 DEPS = [*SRCS, os.path.join(_HERE, "csrc", "az_games.hip.h"),
         os.path.join(os.path.dirname(_HERE), "include", "az_engine.h")]
 LIB_DIR = os.path.join(_HERE, "lib")

@@ -47,7 +47,7 @@ EXPORTS = ["az_create", "az_destroy", "az_get_dims", "az_last_error", "az_check"
            "az_tower_heads_forward_static", "az_static_max_boards", "az_tower_forward_f32", "az_heads_forward_f32",
            "az_select_wave", "az_expand_wave", "az_search_remaining", "az_set_virtual_loss", "az_smallnet_forward_f32",
            "az_quick_tower_forward_f32", "az_quick_heads_forward_f32", "az_quick_stash_bytes", "az_quick_tower_forward", "az_quick_heads_forward",
-           "az_smallnet_head_floats", "az_draw_rng", "az_philox4x32_10", "az_tower_forward_h2", "az_tower_forward_h1"]
+           "az_smallnet_head_floats", "az_draw_rng", "az_philox4x32_10", "az_tower_forward_h2", "az_tower_forward_h1", "az_tower_forward_f32w"]
 
 _lib = None
 
@@ -96,6 +96,7 @@ def load_library() -> C.CDLL:
     lib.az_static_max_boards.restype = C.c_int32
     lib.az_tower_heads_forward_static.argtypes = [C.c_int32] * 4 + [vp] * 14 + [C.c_float, vp, vp, vp]
     lib.az_tower_forward_f32.argtypes = [C.c_int32] * 4 + [vp] * 10 + [C.c_int32, vp]
+    lib.az_tower_forward_f32w.argtypes = [C.c_int32] * 4 + [vp] * 10 + [C.c_int32, vp]
     lib.az_heads_forward_f32.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]
     lib.az_smallnet_forward_f32.argtypes = [C.c_int32, C.c_int32] + [vp] * 12
     lib.az_smallnet_head_floats.argtypes = [C.c_int32]

@@ -60,6 +60,19 @@ def _pack3x3_f32(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
     return t.permute(0, 1, 2, 4, 3).contiguous().float()
 
 
+def _pack_winograd_f32(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
+    """(co 64, ci, 3, 3) f32 -> U = G g G^T of every filter (Winograd F(2x2, 3x3); computed in f64, rounded to f32 once) laid out
+    [stage ci/8][j 2][kq 4][co tile 4][i 4][co 16][q 4] f32 (csrc/az_tower_w.hip): input channel 8 stage + 2 kq + j, transform
+    point (i, q), output channel 16 tile + co"""
+    co, ci = w.shape[0], w.shape[1]
+    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    u = (g @ w.double() @ g.t()).float()  # (co, ci, 4, 4)
+    if ci < cin_pad:
+        u = torch.cat([u, u.new_zeros(co, cin_pad - ci, 4, 4)], 1)
+    t = u.reshape(4, 16, cin_pad // 8, 4, 2, 4, 4)  # ct, co16, stage, kq, j, i, q
+    return t.permute(2, 4, 3, 0, 5, 1, 6).contiguous()
+
+
 def _h2_scale(w: torch.Tensor) -> float:
     """the power of two SW with max |w| * SW in (2^13, 2^14] (csrc/az_tower_h2.hip: both f16 halves of w * SW stay in f16's
     normal range for weights down to 2^-14 of the largest), capped to [1, 2^20]"""
@@ -221,6 +234,11 @@ class FusedTowerEvaluator:
         return (cls.supports(model) and cls.quick_shape(model) is None and model._shared_layers[0].out_channels == 64
                 and model._policy_head[4].in_features == 225)
 
+    @classmethod
+    def winograd_supports(cls, model: nn.Module) -> bool:
+        """the Winograd f32 tower (csrc/az_tower_w.hip; precision "f32w"): 64-channel GomokuModel family on 15x15, <= 40 conv layers"""
+        return cls.row_tile_supports(model) and 2 * (len(model._shared_layers) - 3) <= 40
+
     def __init__(self, model: nn.Module, precision: str = "bf16"):
         """precision: "bf16" (az_tower.hip: bf16 operands, f32 accumulation -- the throughput mode), "f32"
         (az_tower_f32.hip: f32 MFMA, the reference's own arithmetic), "bf16r" / "f16" (az_tower_h1.hip, 15x15 / 64 channels:
@@ -233,14 +251,17 @@ class FusedTowerEvaluator:
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
             raise EngineError("FusedTowerEvaluator needs the model on a GPU")
-        if precision not in ("bf16", "f32", "f16x2", "f16", "bf16r"):
-            raise EngineError("FusedTowerEvaluator: precision must be 'bf16', 'f32', 'f16x2', 'f16' or 'bf16r'")
+        if precision not in ("bf16", "f32", "f32w", "f16x2", "f16", "bf16r"):
+            raise EngineError("FusedTowerEvaluator: precision must be 'bf16', 'f32', 'f32w', 'f16x2', 'f16' or 'bf16r'")
         self.quick = self.quick_shape(model)
         if precision == "f16x2" and (self.quick is not None or model._shared_layers[0].out_channels != 64):
             raise EngineError("FusedTowerEvaluator: the f16x2 tower covers 64-channel GomokuModel-family networks")
         if precision in ("f16", "bf16r") and (self.quick is not None or model._shared_layers[0].out_channels != 64
                                               or model._policy_head[4].in_features != 225):
             raise EngineError("FusedTowerEvaluator: the row-tile tower (f16 / bf16r) covers 64-channel GomokuModel-family networks on 15x15")
+        if precision == "f32w" and not self.winograd_supports(model):
+            raise EngineError("FusedTowerEvaluator: the Winograd f32 tower (f32w) covers 64-channel GomokuModel-family networks on 15x15, "
+                              "at most 20 residual blocks")
         if self.quick is not None:
             self.board, self.ch, self.q_blocks, self.q_layers = self.quick
             self.n2 = self.board * self.board
@@ -332,7 +353,7 @@ class FusedTowerEvaluator:
         scale_of = ((lambda w: 1.0) if self.precision == "bf16r" else
                     (lambda w: 1.0 if float(w.abs().max()) >= 2.0 ** -6 else min(_h2_scale(w), 32768.0)) if h1 else _h2_scale)
         pack_h = (lambda w, cin, sc: _pack3x3_h1(w, cin, sc, h1_dtype)) if h1 else _pack3x3_h2
-        pack3 = _pack3x3_f32 if self.precision == "f32" else _pack3x3
+        pack3 = _pack3x3_f32 if self.precision == "f32" else _pack_winograd_f32 if self.precision == "f32w" else _pack3x3
         w, b = _fold(sl[0], sl[1])
         scales = [scale_of(w)] if h2 else None
         _keep(self, "w0", _pack_stem_h1(w, scales[0], h1_dtype) if h1 else pack_h(w, 32, scales[0]) if h2 else pack3(w, 16), dev)
@@ -446,6 +467,12 @@ class FusedTowerEvaluator:
             rc = self.lib.az_tower_forward_h2(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
                                               flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.sw), P(self.headw), P(self.headb),
                                               P(feat), self.feat_stride, P(self.overflow), st)
+        elif self.precision == "f32w":
+            if list_p is not None:
+                raise EngineError("the Winograd f32 tower takes the packed batch with flags (or all slots), not a compact list")
+            rc = self.lib.az_tower_forward_f32w(self.board, self.ch, B, self.n_layers, P(x) if x is not None else None, ring_p, leaf_p,
+                                                flags_p, P(self.w0), P(self.wl), P(self.bias), P(self.headw), P(self.headb),
+                                                P(feat), self.feat_stride, st)
         elif self.precision == "f32":
             if list_p is not None:
                 raise EngineError("the f32 tower takes the packed batch with flags (or all slots), not a compact list")

@@ -266,6 +266,22 @@ int az_tower_forward_h1(int32_t board_size, int32_t channels, int32_t n_boards, 
                         const float *headw_dev, const float *headb_dev, void *feat_dev, int32_t feat_bf16, int32_t feat_stride,
                         int32_t *overflow_dev, void *stream);
 
+/* Winograd f32 tower (csrc/az_tower_w.hip): the 15x15, 64-channel GomokuModel-family trunk (the network az_tower_forward_f32
+ * evaluates; model contract nn_models/base.py:17-19, examples/gomoku/model.py:41-90) in plain f32 arithmetic -- f32 operands,
+ * f32 products and sums on v_mfma_f32_16x16x4_f32 -- with the 3x3 convolutions computed by the Winograd transform F(2x2, 3x3)
+ * (the algorithm cuDNN / MIOpen choose for f32 3x3 convolutions): 2.1x fewer MFMAs than the direct convolution of
+ * az_tower_forward_f32, same accuracy class, not bit-equal to it (another summation order).
+ * Same inputs (dense f32 planes, or the packed leaf batch + flags) and f32 feature rows as az_tower_forward_f32; finish with
+ * az_heads_forward_f32.  Weights = G g G^T of the BN-folded filters (alphazero_amd.fused._pack_winograd_f32):
+ *   u0_dev [stage 2][j 2][kq 4][co tile 4][i 4][co 16][q 4] f32 (input channel 8 stage + 2 kq + j, 9 of 16 used; transform
+ *   point (i, q); output channel 16 tile + co), ul_dev [n_conv_layers][stage 8][...] likewise;
+ *   bias_dev [1 + n_conv_layers][64], headw_dev (3, 64), headb_dev (3) f32 as az_tower_forward_f32.
+ * board_size 15, channels 64, n_conv_layers even, <= 40. */
+int az_tower_forward_f32w(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const float *x_f32_dev,
+                          const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev, const void *u0_dev,
+                          const void *ul_dev, const float *bias_dev, const float *headw_dev, const float *headb_dev,
+                          float *feat_f32_dev, int32_t feat_stride, void *stream);
+
 /* EXPLORATORY, SECONDARY (csrc/az_tower_h2.hip): the 64-channel GomokuModel-family tower (the network az_tower_forward_f32
  * evaluates; model contract nn_models/base.py:17-19) at f32-LEVEL ACCURACY on the f16 MFMA pipe -- every f32 operand split
  * into two f16 halves (22 significant bits), w x = w1 x1 + w1 x2 + w2 x1 on v_mfma_f32_16x16x32_f16 with f32 accumulation.
