@@ -142,7 +142,9 @@ class SelfPlayRunner:
                 if prec == "bf16" and not isinstance(fused, str) and FusedTowerEvaluator.row_tile_supports(model):
                     prec = "bf16r"  # the same arithmetic on the row-tile tower (the runner feeds the packed batch: no dense dtype involved)
                 if isinstance(fused, str):
-                    if fused not in ("f32", "bf16", "f16x2", "f16", "bf16r") or (fused in ("f32", "bf16") and fused != prec.rstrip("r")):
+                    # fused="f32w" (f32 engine, 15x15 / 64 channels): az_tower_w.hip, the f32 tower with Winograd-transformed convolutions
+                    if fused not in ("f32", "f32w", "bf16", "f16x2", "f16", "bf16r") or (fused in ("f32", "bf16") and fused != prec.rstrip("r")) \
+                            or (fused == "f32w" and prec != "f32"):
                         raise EngineError(f"fused={fused!r} does not fit an engine with nn_dtype {engine.nn_dtype}")
                     prec = fused
                 self.fused = FusedTowerEvaluator(model, prec)

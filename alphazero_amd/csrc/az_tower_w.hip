@@ -54,6 +54,7 @@ constexpr int ZERO_OFF = N * RSB;             // a cell of zeros: every patch el
 constexpr int DUMP_OFF = ZERO_OFF + CSB;      // where the outputs of the 16th row / column go
 constexpr int ACT_BYTES = (DUMP_OFF + CSB + 15) / 16 * 16;
 constexpr int STAGE_BYTES = 32768;            // U of 8 input channels: [j 2][kq 4][ct 4][pg 4][co 16][4 points] f32
+constexpr int KSTEP_BYTES = STAGE_BYTES / 2;  // one k-step (j): 4 input channels, one per 16-lane group kq
 constexpr int MAX_LAYERS = 40;                // bias rows kept in LDS
 constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = 8 * SWB;  // packed input: 8 states x 2 colours x 8 words
 constexpr int NTH = 512;
@@ -68,64 +69,134 @@ constexpr int LDS_BYTES = OFF_SL + 8 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 static_assert(OFF_BL % 16 == 0 && OFF_HW % 16 == 0 && OFF_HP % 16 == 0 && OFF_RG % 16 == 0, "alignment");
 
+#ifndef AZ_W_ABLATE
+#define AZ_W_ABLATE 0  // diagnostic builds (wrong results, timing only): 1 no patch reads / input transform, 2 no stage barriers,
+#endif                 // 4 no U reads, 8 no MFMAs, 16 no stage DMA
+
+#ifndef AZ_W_STAMP
+#define AZ_W_STAMP 0  // diagnostic build: s_memtime stamps of workgroup 7's sixth board, per wave (az_debug_w_stamps)
+#endif
+#if AZ_W_STAMP
+static __device__ unsigned long long g_w_stamps[8 * 32];
+#define WSTAMP(k) do { if (stamp_on && lane == 0) g_w_stamps[wave * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
+
 #define LDS_PTR(T, a) ((__attribute__((address_space(3))) T *)(uintptr_t)(a))
 __device__ __forceinline__ f32x2 lds_r2(uint32_t a) { return *LDS_PTR(const f32x2, a); }
 __device__ __forceinline__ f32x4 lds_r4(uint32_t a) { return *LDS_PTR(const f32x4, a); }
 __device__ __forceinline__ void lds_w2(uint32_t a, f32x2 v) { *LDS_PTR(f32x2, a) = v; }
 
-// async global -> LDS copy of 16 B per lane: the LDS destination is the wave-uniform `lds_base` + lane * 16
-__device__ __forceinline__ void glds16(const char *g_lane, uint32_t lds_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane,
-                                   (__attribute__((address_space(3))) void *)(uintptr_t)lds_base, 16, 0, 0);
+// async global -> LDS copy of 16 B per lane (LDS-DMA): the LDS destination is the wave-uniform `lds_base` + lane * 16.  Issued from
+// inline assembly ON PURPOSE: the compiler makes every LDS read that might alias an LDS-DMA it knows of wait for vmcnt(0), which
+// would serialise the weight stream that runs three k-steps ahead of its use; the reads of a buffer are ordered behind its DMA by
+// hand (conv_w: vmcnt(2) + barrier).  A copy the compiler does not see can only make ITS OWN vmcnt waits stricter, never weaker.
+// (address = wave-uniform 64-bit base in SGPRs + the lane's 32-bit byte offset: no VALU, no 64-bit VGPR pointers.)
+__device__ __forceinline__ void glds16(const char *g_base, uint32_t lane_off, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_base), "v"(lane_off), "s"(g_base) : "memory");
 }
-// one stage of U (32 KiB, contiguous in global memory and in LDS alike): 1 KiB per wave-instruction, 4 per wave
-__device__ __forceinline__ void stage_dma(const char *src, uint32_t dst, int wave, int lane) {
+// workgroup barrier that orders LDS accesses only: __syncthreads() also drains every outstanding LDS-DMA (vmcnt(0)), which
+// would serialise the weight stream that runs three k-steps ahead; what has to have landed is waited for explicitly (vmcnt(2))
+// (a workgroup fence, even one restricted to the local address space, makes the compiler wait for the LDS-DMA too: the wave's own
+// LDS accesses are drained by hand, and the "memory" clobber keeps the compiler from moving accesses across the barrier)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// one k-step of U (16 KiB, contiguous in global memory and in LDS alike): 1 KiB per wave-instruction, 2 per wave
+__device__ __forceinline__ void kstep_dma(const char *src, uint32_t dst, int wave, int lane) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) glds16(src + (p * 8 + wave) * 1024 + lane * 16, dst + (p * 8 + wave) * 1024);
+  for (int p = 0; p < 2; ++p) glds16(src + (p * 8 + wave) * 1024, (uint32_t)lane * 16u, dst + (p * 8 + wave) * 1024);
 }
 
-// One conv layer in the transform domain: acc[point][ct] += U V over `ns` stages of 8 input channels.  On entry the layer's
-// stage 0 is on its way into buffer `buf`; the last stage prefetches `wnext` (stage 0 of whatever runs next).  A stage:
-// wait for its weights, barrier (every wave has also finished the stage before: the other buffer is free), start the next
-// stage's DMA, then per wave 16 patch reads -> V (registers) -> 2 k-steps x (8 ds_read_b128 of U, 32 MFMAs).
-__device__ __forceinline__ void conv_w(uint32_t lds0, const uint32_t (&pa)[16], uint32_t abase, const char *wg, const char *wnext, int ns,
-                                       int wave, int lane, int &buf, f32x4 (&acc)[16][2]) {
-#pragma unroll 1
-  for (int s = 0; s < ns; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    stage_dma(s + 1 < ns ? wg + (size_t)(s + 1) * STAGE_BYTES : wnext, lds0 + (uint32_t)((buf ^ 1) * STAGE_BYTES), wave, lane);
-    const uint32_t so = (uint32_t)s * 32u;
-    f32x2 d[4][4];
+// the lane's 4x4 patch of its two input channels of stage `so / 32` (16 ds_read_b64; `so` is a compile-time constant at every
+// call: the offset travels in the instruction)
+__device__ __forceinline__ void patch_read(const uint32_t (&pa)[16], uint32_t so, f32x2 (&d)[16]) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) d[i >> 2][i & 3] = lds_r2(pa[i] + so);
-    f32x2 t[4][4], v[4][4];
+  for (int i = 0; i < 16; ++i) {
+    if (AZ_W_ABLATE & 1) d[i] = (f32x2){__uint_as_float(pa[i] + so), 1.0f};
+    else d[i] = lds_r2(pa[i] + so);
+  }
+}
+// V = B^T d B (32 two-channel adds), point 4 i + q
+__device__ __forceinline__ void patch_transform(const f32x2 (&d)[16], f32x2 (&v)[16]) {
+  f32x2 t[16];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {  // B^T d
-      t[0][c] = d[0][c] - d[2][c];
-      t[1][c] = d[1][c] + d[2][c];
-      t[2][c] = d[2][c] - d[1][c];
-      t[3][c] = d[1][c] - d[3][c];
+  for (int c = 0; c < 4; ++c) {  // B^T d
+    t[c] = d[c] - d[8 + c];
+    t[4 + c] = d[4 + c] + d[8 + c];
+    t[8 + c] = d[8 + c] - d[4 + c];
+    t[12 + c] = d[4 + c] - d[12 + c];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // (B^T d) B
+    v[4 * i] = t[4 * i] - t[4 * i + 2];
+    v[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
+    v[4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
+    v[4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+  }
+}
+// the 32 MFMAs of a k-step (channel J of the lane's pair): 16 points x 2 channel tiles.  U comes from the k-step's buffer at
+// `ab` in 8 ds_read_b128, each requested one group of four MFMAs ahead: group 0 arrives in `a` (requested during the k-step
+// before), and the last group's slot requests group 0 of the NEXT k-step from `abn` (its buffer has landed and is visible:
+// conv_w) -- no U read is waited for right after a barrier.  FIRST: the layer's first k-step -- only the four points that
+// carry bias / residual (0, 3, 12, 15) have live accumulators, the others start from the instruction's zero operand.
+template <bool FIRST, bool LAST, int J>
+__device__ __forceinline__ void kstep_mfma(uint32_t ab, uint32_t abn, f32x4 &a, const f32x2 (&v)[16], f32x4 (&acc)[16][2]) {
+  auto uread = [&](uint32_t base, int g) -> f32x4 {
+    if (AZ_W_ABLATE & 4) return (f32x4){__uint_as_float(base), 1.0f, 2.0f, 3.0f};
+    return lds_r4(base + (uint32_t)((g & 1) * 1024 + (g >> 1) * 256));
+  };
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {  // group g: point row i = g >> 1, channel tile ct = g & 1
+    const int i = g >> 1, ct = g & 1;
+    f32x4 an = a;
+    if (g + 1 < 8) an = uread(ab, g + 1);
+    else if (!LAST) an = uread(abn, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = 4 * i + q;
+      const bool fresh = FIRST && !(p == 0 || p == 3 || p == 12 || p == 15);
+      if (AZ_W_ABLATE & 8) acc[p][ct][q] = (fresh ? 0.0f : acc[p][ct][q]) + a[q] * v[p][J];
+      else acc[p][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], v[p][J], fresh ? (f32x4){0.0f, 0.0f, 0.0f, 0.0f} : acc[p][ct], 0, 0, 0);
     }
+    a = an;
+  }
+}
+
+// One conv layer in the transform domain: acc[point][ct] = (preloaded bias / residual) + U V over T = 2 NS k-steps of 4 input
+// channels (per lane: one), fully unrolled -- every LDS offset is an instruction immediate.  U streams through FOUR 16 KiB
+// buffers, k-step t in buffer t & 3 (T is a multiple of 4: every layer starts in buffer 0), three k-steps ahead of its use and
+// straight across layer and board boundaries (after this layer's last k-step the stream continues with `wnext`: the next
+// layer, or the next board's stem).  Top of k-step t: wait until the DMA of k-step t + 1 has landed (the one of t + 2 may be in
+// flight: vmcnt(2)), barrier -- every wave has finished k-step t - 1, whose buffer is the one k-step t + 3 goes to, and k-step
+// t + 1's buffer is now complete and visible to all, so its first U read may be issued during k-step t -- then the 32 MFMAs on
+// the V formed one stage (two k-steps) ago; the next stage's patch is requested between the stage's two k-steps and
+// transformed after the second.  f32 MFMAs and ordinary VALU instructions share the SIMD's multipliers (nothing co-executes:
+// az_tower_f32.hip), so every VALU instruction in this loop is MFMA time: immediates, no address arithmetic.
+template <int NS>
+__device__ __forceinline__ void conv_w(uint32_t lds0, const uint32_t (&pa)[16], uint32_t abase, const char *wg, const char *wnext,
+                                       int wave, int lane, f32x4 (&acc)[16][2]) {
+  constexpr int T = 2 * NS;
+  static_assert(T % 4 == 0, "a layer ends in the buffer it started in");
+  f32x2 d[16], v[16];
+  f32x4 a;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // (B^T d) B
-      v[i][0] = t[i][0] - t[i][2];
-      v[i][1] = t[i][1] + t[i][2];
-      v[i][2] = t[i][2] - t[i][1];
-      v[i][3] = t[i][1] - t[i][3];
+  for (int t = 0; t < T; ++t) {
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (t == 0 || !(AZ_W_ABLATE & 2)) lds_barrier();
+    if (!(AZ_W_ABLATE & 16)) kstep_dma(t + 3 < T ? wg + (size_t)(t + 3) * KSTEP_BYTES : wnext + (size_t)(t + 3 - T) * KSTEP_BYTES,
+                                       lds0 + (uint32_t)(((t + 3) & 3) * KSTEP_BYTES), wave, lane);
+    const uint32_t ab = abase + (uint32_t)((t & 3) * KSTEP_BYTES), abn = abase + (uint32_t)(((t + 1) & 3) * KSTEP_BYTES);
+    if (t == 0) {
+      a = lds_r4(ab);
+      patch_read(pa, 0u, d);
+      patch_transform(d, v);
     }
-    const uint32_t ab = abase + (uint32_t)(buf * STAGE_BYTES);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 a = lds_r4(ab + (uint32_t)(j * 16384 + ct * 1024 + i * 256));
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[4 * i + q][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], v[i][q][j], acc[4 * i + q][ct], 0, 0, 0);
-        }
-    buf ^= 1;
+    if (t == 0) kstep_mfma<true, false, 0>(ab, abn, a, v, acc);
+    else if (t + 1 == T) kstep_mfma<false, true, 1>(ab, abn, a, v, acc);
+    else if (t & 1) kstep_mfma<false, false, 1>(ab, abn, a, v, acc);
+    else kstep_mfma<false, false, 0>(ab, abn, a, v, acc);
+    if (!(t & 1) && t + 2 < T) patch_read(pa, (uint32_t)(t / 2 + 1) * 32u, d);
+    if ((t & 1) && t + 1 < T) patch_transform(d, v);
   }
 }
 
@@ -164,20 +235,17 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     const int r = 2 * ty + (i >> 1), c = 2 * tx + (i & 1);
     oc[i] = act0 + (uint32_t)((r < N && c < N ? r * RSB + c * CSB : DUMP_OFF) + (32 * chalf + 4 * kq) * 4);
   }
-  const uint32_t abase = lds0 + (uint32_t)(kq * 4096 + chalf * 2048 + n * 16);
+  const uint32_t abase = lds0 + (uint32_t)(kq * 4096 + chalf * 2048 + n * 16);  // U of a k-step: [kq 4][ct 4][i 4][co 16][q 4]
   const int bo = 32 * chalf + 4 * kq;  // first of the lane's channels (ct adds 16)
 
-  int buf = 0;
-  stage_dma(u0, lds0, wave, lane);
+  for (int t = 0; t < 3; ++t) kstep_dma(u0 + t * KSTEP_BYTES, lds0 + (uint32_t)(t * KSTEP_BYTES), wave, lane);  // the stem's first three k-steps
   if (tid == 0) { slots[1] = (int)blockIdx.x; slots[2] = -1; }
   __syncthreads();
 
   f32x4 acc[16][2];
-  auto preload = [&](const f32x4 (&pre)[4][2]) {  // A^T M A sends M[0][0], -M[0][3], -M[3][0], M[3][3] to outputs 00, 01, 10, 11
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[p][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  // A^T M A sends M[0][0], -M[0][3], -M[3][0], M[3][3] to outputs 00, 01, 10, 11: the accumulators of these four points carry
+  // bias (+ residual) into the layer; the other twelve start from the first MFMA's zero operand (stage_mfma<true>)
+  auto preload = [&](const f32x4 (&pre)[4][2]) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       acc[0][ct] = pre[0][ct];
@@ -189,22 +257,20 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
   // inverse transform, ReLU, store in place; the next layer's accumulators start at its bias (+ the activations this lane
   // overwrites, when they are the residual of the block's second conv)
   auto epilogue = [&](bool with_res, const float *bnext) {
-    float y[4][2][4];  // [output 2 a + b][ct][r]
+    f32x4 y[4][2];  // [output 2 a + b][ct] (4 channels r)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 2; ++ct) {
+      f32x4 s0[4], s1[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          s0[q] = (acc[q][ct][r] + acc[4 + q][ct][r]) + acc[8 + q][ct][r];
-          s1[q] = (acc[4 + q][ct][r] - acc[8 + q][ct][r]) - acc[12 + q][ct][r];
-        }
-        y[0][ct][r] = (s0[0] + s0[1]) + s0[2];
-        y[1][ct][r] = (s0[1] - s0[2]) - s0[3];
-        y[2][ct][r] = (s1[0] + s1[1]) + s1[2];
-        y[3][ct][r] = (s1[1] - s1[2]) - s1[3];
+      for (int q = 0; q < 4; ++q) {
+        s0[q] = (acc[q][ct] + acc[4 + q][ct]) + acc[8 + q][ct];
+        s1[q] = (acc[4 + q][ct] - acc[8 + q][ct]) - acc[12 + q][ct];
       }
+      y[0][ct] = (s0[0] + s0[1]) + s0[2];
+      y[1][ct] = (s0[1] - s0[2]) - s0[3];
+      y[2][ct] = (s1[0] + s1[1]) + s1[2];
+      y[3][ct] = (s1[1] - s1[2]) - s1[3];
+    }
     f32x4 pre[4][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -225,7 +291,15 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     preload(pre);
   };
 
+#if AZ_W_STAMP
+  int it = 0;
+#endif
   for (;;) {
+#if AZ_W_STAMP
+    const bool stamp_on = blockIdx.x == 7 && it == 6;
+    ++it;
+#endif
+    WSTAMP(0);
     if (tid == 0) {  // this board: the ticket drawn ahead, or -- when its leaf is terminal (flag off) -- the next that is not
       int tk = slots[1], fl = slots[2];
       while (tk < G && flags != nullptr) {
@@ -239,6 +313,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     __syncthreads();
     const int g = slots[0];
     if (g >= G) break;
+    WSTAMP(1);
     unsigned int drawn = 0;
     if (tid == 0) drawn = atomicAdd(&tickets[0], 1u);  // the next ticket (lands while the input is fetched)
     if (x == nullptr) {
@@ -280,19 +355,30 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
       preload(pre);
     }
     // (the first stage's barrier orders the input planes before the patch reads)
-    conv_w(lds0, pa, abase, u0, L > 0 ? ul : u0, 2, wave, lane, buf, acc);
+    WSTAMP(3);
+    conv_w<2>(lds0, pa, abase, u0, L > 0 ? ul : u0, wave, lane, acc);
+    WSTAMP(4);
     __syncthreads();  // every wave has read the layer's input: the outputs may overwrite it
+    WSTAMP(5);
     epilogue(false, L > 0 ? bl + C : nullptr);
+    WSTAMP(6);
     for (int l = 0; l < L; l += 2) {
       const char *w1 = ul + (size_t)l * 8 * STAGE_BYTES, *w2 = w1 + (size_t)8 * STAGE_BYTES;
-      conv_w(lds0, pa, abase, w1, w2, 8, wave, lane, buf, acc);
+      conv_w<8>(lds0, pa, abase, w1, w2, wave, lane, acc);
+      WSTAMP(7 + 3 * l);
       __syncthreads();
+      WSTAMP(8 + 3 * l);
       epilogue(true, bl + (2 + l) * C);
-      conv_w(lds0, pa, abase, w2, l + 2 < L ? w2 + (size_t)8 * STAGE_BYTES : u0, 8, wave, lane, buf, acc);
+      WSTAMP(9 + 3 * l);
+      conv_w<8>(lds0, pa, abase, w2, l + 2 < L ? w2 + (size_t)8 * STAGE_BYTES : u0, wave, lane, acc);
+      WSTAMP(10 + 3 * l);
       __syncthreads();
+      WSTAMP(11 + 3 * l);
       epilogue(false, l + 2 < L ? bl + (3 + l) * C : nullptr);
+      WSTAMP(12 + 3 * l);
     }
     __syncthreads();
+    WSTAMP(28);
     // ---- heads: the three 1x1 convs + ReLU from the finished activations: a thread takes a cell and half of its channels
     for (int e = tid; e < 2 * NV; e += NTH) {
       const int half = e >= NV ? 1 : 0, cell = e - half * NV, row = cell / N, col = cell - row * N;
@@ -313,7 +399,9 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
       hp[(half * 3 + 1) * NV + cell] = s1;
       hp[(half * 3 + 2) * NV + cell] = s2;
     }
+    WSTAMP(29);
     __syncthreads();
+    WSTAMP(30);
     // feature rows [policy NV | pad to 16 | value0 NV | value1 NV | pad]: whole-wave consecutive 4-byte stores
     constexpr int KP = (NV + 15) / 16 * 16;
     float *fr = feat + (size_t)g * FS;
@@ -323,6 +411,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
       fr[(k == 0 ? 0 : KP + (k - 1) * NV) + cell] = fmaxf(v + hw[3 * C + k], 0.0f);
     }
     // (the next board's first barriers order these reads of hp / act before anything overwrites them)
+    WSTAMP(31);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stage prefetched last must have landed before the LDS is given back
   if (tid == 0 && atomicAdd(&tickets[1], 1u) == gridDim.x - 1) {
@@ -333,6 +422,12 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
 }
 
 }  // namespace aztw
+
+#if AZ_W_STAMP
+extern "C" int az_debug_w_stamps(unsigned long long *out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(aztw::g_w_stamps), sizeof(unsigned long long) * 8 * 32) == hipSuccess ? 0 : -3;
+}
+#endif
 
 static std::mutex g_w_mutex;
 static bool g_w_attr_done[64];

@@ -148,7 +148,7 @@ def cpu_baseline(workload: str, budget_s: float = 12.0) -> dict:
 
 
 # ------------------------------------------------------------------------------ GPU bench -------
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f16x2": 2500.0, "f16r": 2500.0, "bf16r": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "f32w": 157.3, "bf16": 2500.0, "f16": 2500.0, "f16x2": 2500.0, "f16r": 2500.0, "bf16r": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
 # "f16x2" (az_tower_h2.hip): f32 operands split into two f16 halves, THREE f16 MFMAs per product block, f32 accumulation --
 # f32-level accuracy on the f16 pipe.  Its roofline counts the flops the MFMA pipe executes (3 x the convolution's) against the
 # f16 peak; the convolution's own flops per second are reported beside it as f32_equivalent_tflops.
@@ -169,12 +169,12 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     game, n, sims, slots, _ = WORKLOADS[args.workload]
     sims = args.sims or sims
     slots = args.slots or slots
-    tdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f16x2": torch.float32, "f16r": torch.float32,
-              "bf16r": torch.float32}[dtype_name]
+    tdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32w": torch.float32, "f16x2": torch.float32,
+              "f16r": torch.float32, "bf16r": torch.float32}[dtype_name]
     h2 = dtype_name == "f16x2"
     # towers asked for by name on an f32 engine: az_tower_h2.hip ("f16x2"), az_tower_h1.hip (the row-tile tower: "f16r" = f16
     # operands, "bf16r" = bf16 operands)
-    named_tower = {"f16x2": "f16x2", "f16r": "f16", "bf16r": "bf16r"}.get(dtype_name)
+    named_tower = {"f16x2": "f16x2", "f16r": "f16", "bf16r": "bf16r", "f32w": "f32w"}.get(dtype_name)
     model = make_model(args.workload).to(dev)
     if tdtype != torch.float32:
         model = model.to(tdtype)
@@ -445,7 +445,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     r02_bytes = (20.0 * st["sum_children"] + fixed_sel + 12.0 * st["expanded_edges"] + fixed_exp) / launches
     # the tree work of a simulation step is ONE launch: backup of simulation i + descent of simulation i+1
     dom = ("k_expand_select", sel_bytes + exp_bytes, tree_ms)
-    tower_kernel = "k_smallnet_f32" if game != 2 else ("k_tower_f32_t16" if dtype_name == "f32" else "k_tower_h2" if h2 else "k_tower_h1" if named_tower else "k_tower")
+    tower_kernel = "k_smallnet_f32" if game != 2 else ("k_tower_f32_t16" if dtype_name == "f32" else "k_tower_f32w" if dtype_name == "f32w" else
+                                                       "k_tower_h2" if h2 else "k_tower_h1" if named_tower else "k_tower")
 
     # HBM traffic from PMC counters cannot be collected inside this run (separate rocprofv3 --pmc passes,
     # scripts/pmc_traffic.sh); the last committed measurement of this same workload is reported, if present
@@ -728,7 +729,7 @@ def main():
     ap.add_argument("--workload", default="gomoku15", choices=sorted(WORKLOADS))
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--sims", type=int, default=0)
-    ap.add_argument("--dtype", default="auto", choices=["auto", "bf16", "f16", "f32", "f16x2", "f16r", "bf16r"],
+    ap.add_argument("--dtype", default="auto", choices=["auto", "bf16", "f16", "f32", "f32w", "f16x2", "f16r", "bf16r"],
                     help="network arithmetic of the PRIMARY line.  auto = f32, the reference's own precision (nn_models/base.py:17-19): the "
                          "hand-written f32 kernels for the GomokuModel / QuickModel families and the two small nets, the module's own PyTorch forward otherwise")
     ap.add_argument("--secondary-steps", type=int, default=-1, help="timed steps of the second line at the other precision (bf16 "

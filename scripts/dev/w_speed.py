@@ -31,3 +31,26 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in ev.kernel_events)[len(ev.kernel_events) // 2]
         print(f"{prec}: {ms:.3f} ms per {B} boards = {flops / ms / 1e9:.0f} TFLOP/s of direct-convolution flops", flush=True)
+    import ctypes as C
+
+    from alphazero_amd.engine import load_library
+    lib = load_library()
+    if hasattr(lib, "az_debug_w_stamps"):  # a -DAZ_W_STAMP=1 build: phase boundaries of one board (workgroup 7, its sixth), s_memtime ticks (100 MHz)
+        ev = FusedTowerEvaluator(net, "f32w")
+        ev(x.contiguous())
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * 256)()
+        lib.az_debug_w_stamps.argtypes = [C.c_void_p]
+        assert lib.az_debug_w_stamps(buf) == 0
+        names = {0: "top", 1: "slot known", 2: "input words in", 3: "expanded, preload", 4: "stem conv", 5: "barrier", 6: "stem epilogue"}
+        for l in range(0, 2 * blocks, 2):
+            names.update({7 + 3 * l: f"conv {l}", 8 + 3 * l: "barrier", 9 + 3 * l: "epilogue (res)", 10 + 3 * l: f"conv {l + 1}", 11 + 3 * l: "barrier", 12 + 3 * l: "epilogue"})
+        names.update({28: "barrier", 29: "heads", 30: "barrier", 31: "feature rows"})
+        for w in (0, 3, 7):
+            t = [buf[w * 32 + k] for k in range(32)]
+            print(f"wave {w}: board total {(t[31] - t[0]) * 10} ns")
+            prev = t[0]
+            for k in sorted(names):
+                if t[k]:
+                    print(f"   {names[k]:>18}: +{(t[k] - prev) * 10:6d} ns")
+                    prev = t[k]
