@@ -145,12 +145,14 @@ __device__ __forceinline__ void kstep_mfma(uint32_t ab, uint32_t abn, f32x4 &a, 
     if (AZ_W_ABLATE & 4) return (f32x4){__uint_as_float(base), 1.0f, 2.0f, 3.0f};
     return lds_r4(base + (uint32_t)((g & 1) * 1024 + (g >> 1) * 256));
   };
+  f32x4 a0n = a;  // group 0 of the next k-step: requested half a k-step before the barrier that follows this one
 #pragma unroll
   for (int g = 0; g < 8; ++g) {  // group g: point row i = g >> 1, channel tile ct = g & 1
     const int i = g >> 1, ct = g & 1;
     f32x4 an = a;
     if (g + 1 < 8) an = uread(ab, g + 1);
-    else if (!LAST) an = uread(abn, 0);
+    else an = a0n;
+    if (g == 3 && !LAST) a0n = uread(abn, 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int p = 4 * i + q;
@@ -191,11 +193,14 @@ __device__ __forceinline__ void conv_w(uint32_t lds0, const uint32_t (&pa)[16], 
       patch_read(pa, 0u, d);
       patch_transform(d, v);
     }
+    if ((t & 1) && t + 1 < T) {  // in flight under this k-step's MFMAs (left alone the scheduler sinks them to the barrier to save registers)
+      patch_read(pa, (uint32_t)(t / 2 + 1) * 32u, d);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (t == 0) kstep_mfma<true, false, 0>(ab, abn, a, v, acc);
     else if (t + 1 == T) kstep_mfma<false, true, 1>(ab, abn, a, v, acc);
     else if (t & 1) kstep_mfma<false, false, 1>(ab, abn, a, v, acc);
     else kstep_mfma<false, false, 0>(ab, abn, a, v, acc);
-    if (!(t & 1) && t + 2 < T) patch_read(pa, (uint32_t)(t / 2 + 1) * 32u, d);
     if ((t & 1) && t + 1 < T) patch_transform(d, v);
   }
 }
@@ -229,14 +234,11 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     const int r = 2 * ty - 1 + (i >> 2), c = 2 * tx - 1 + (i & 3);
     pa[i] = act0 + (uint32_t)((r >= 0 && r < N && c >= 0 && c < N ? r * RSB + c * CSB : ZERO_OFF) + kq * 8);
   }
-  uint32_t oc[4];  // the lane's 2x2 outputs: channels 32 chalf + 16 ct + 4 kq .. + 3
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = 2 * ty + (i >> 1), c = 2 * tx + (i & 1);
-    oc[i] = act0 + (uint32_t)((r < N && c < N ? r * RSB + c * CSB : DUMP_OFF) + (32 * chalf + 4 * kq) * 4);
-  }
+  // Everything the epilogues need per lane (its output cells, its channels) is re-derived from a laundered copy of the lane index
+  // inside each epilogue: hoisted out of the board loop these values would sit in registers through the conv loops, which run
+  // at the register budget (a spill there is a scratch load, and a scratch load is a vmcnt(0) in the weight stream)
+  auto fresh = [](int x) { asm volatile("" : "+v"(x)); return x; };
   const uint32_t abase = lds0 + (uint32_t)(kq * 4096 + chalf * 2048 + n * 16);  // U of a k-step: [kq 4][ct 4][i 4][co 16][q 4]
-  const int bo = 32 * chalf + 4 * kq;  // first of the lane's channels (ct adds 16)
 
   for (int t = 0; t < 3; ++t) kstep_dma(u0 + t * KSTEP_BYTES, lds0 + (uint32_t)(t * KSTEP_BYTES), wave, lane);  // the stem's first three k-steps
   if (tid == 0) { slots[1] = (int)blockIdx.x; slots[2] = -1; }
@@ -257,6 +259,14 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
   // inverse transform, ReLU, store in place; the next layer's accumulators start at its bias (+ the activations this lane
   // overwrites, when they are the residual of the block's second conv)
   auto epilogue = [&](bool with_res, const float *bnext) {
+    const int ln = fresh(lane), n_ = ln & 15, kq_ = ln >> 4, ty_ = 2 * tg + (n_ >> 3), tx_ = n_ & 7;
+    const int bo = 32 * chalf + 4 * kq_;  // first of the lane's channels (ct adds 16)
+    uint32_t oc[4];                        // the lane's 2x2 outputs
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 2 * ty_ + (i >> 1), c = 2 * tx_ + (i & 1);
+      oc[i] = act0 + (uint32_t)((r < N && c < N ? r * RSB + c * CSB : DUMP_OFF) + bo * 4);
+    }
     f32x4 y[4][2];  // [output 2 a + b][ct] (4 channels r)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
       f32x4 pre[4][2];
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const f32x4 bv = *(const f32x4 *)(bl + bo + 16 * ct);
+        const f32x4 bv = *(const f32x4 *)(bl + 32 * chalf + 4 * (fresh(lane) >> 4) + 16 * ct);
 #pragma unroll
         for (int o = 0; o < 4; ++o) pre[o][ct] = bv;
       }
