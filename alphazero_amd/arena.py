@@ -134,17 +134,22 @@ class SelfPlayRunner:
             if engine.game == GAME_GOMOKU:
                 if engine.nn_dtype not in (torch.bfloat16, torch.float32):
                     raise EngineError("the fused evaluator exists in bf16 and f32: create the engine with one of these nn_dtypes")
-                # the engine's nn_dtype decides: f32 = the reference's own arithmetic (az_tower_f32.hip), bf16 = throughput mode;
-                # fused="f16x2" (f32 engine): az_tower_h2.hip, f32-level accuracy on the f16 MFMA pipe (secondary, by name only);
-                # fused="f16" / "bf16r" (15x15): az_tower_h1.hip, the row-tile tower with one 16-bit product -- "bf16r" is also what
-                # fused=True picks on a bf16 engine when the network fits it
-                prec = "f32" if engine.nn_dtype == torch.float32 else "bf16"
-                if prec == "bf16" and not isinstance(fused, str) and FusedTowerEvaluator.row_tile_supports(model):
-                    prec = "bf16r"  # the same arithmetic on the row-tile tower (the runner feeds the packed batch: no dense dtype involved)
-                if isinstance(fused, str):
-                    # fused="f32w" (f32 engine, 15x15 / 64 channels): az_tower_w.hip, the f32 tower with Winograd-transformed convolutions
-                    if fused not in ("f32", "f32w", "bf16", "f16x2", "f16", "bf16r") or (fused in ("f32", "bf16") and fused != prec.rstrip("r")) \
-                            or (fused == "f32w" and prec != "f32"):
+                # the engine's nn_dtype decides: f32 = the reference's own arithmetic, bf16 = throughput mode.  fused=True picks
+                #   f32 engine: "f32w" (az_tower_w.hip: f32 MFMAs, the 3x3 convolutions by the Winograd transform -- 1.6x the direct
+                #     tower, same accuracy against an f64 evaluation) when the network fits it (15x15, 64 channels), else "f32"
+                #     (az_tower_f32.hip: direct convolution);
+                #   bf16 engine: "bf16r" (az_tower_h1.hip, the row-tile tower) when the network fits it, else "bf16" (az_tower.hip).
+                # By name only: "f16x2" (f32 engine: az_tower_h2.hip, f32-level accuracy on the f16 MFMA pipe, secondary),
+                # "f16" (az_tower_h1.hip with f16 operands), and any of the above to override the choice.
+                base = "f32" if engine.nn_dtype == torch.float32 else "bf16"
+                prec = base
+                if not isinstance(fused, str):
+                    if base == "bf16" and FusedTowerEvaluator.row_tile_supports(model):
+                        prec = "bf16r"  # (the runner feeds the packed batch: no dense dtype involved)
+                    elif base == "f32" and FusedTowerEvaluator.winograd_supports(model):
+                        prec = "f32w"
+                else:
+                    if fused not in ("f32", "f32w", "bf16", "f16x2", "f16", "bf16r") or (fused in ("f32", "f32w", "bf16") and fused.rstrip("w") != base):
                         raise EngineError(f"fused={fused!r} does not fit an engine with nn_dtype {engine.nn_dtype}")
                     prec = fused
                 self.fused = FusedTowerEvaluator(model, prec)

@@ -175,6 +175,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
     # towers asked for by name on an f32 engine: az_tower_h2.hip ("f16x2"), az_tower_h1.hip (the row-tile tower: "f16r" = f16
     # operands, "bf16r" = bf16 operands)
     named_tower = {"f16x2": "f16x2", "f16r": "f16", "bf16r": "bf16r", "f32w": "f32w"}.get(dtype_name)
+    if dtype_name == "f32" and game == 2 and "layers" not in WORKLOADS[args.workload][4]:
+        named_tower = "f32"  # the direct-convolution tower by name (left to itself the runner picks the Winograd tower where it fits)
     model = make_model(args.workload).to(dev)
     if tdtype != torch.float32:
         model = model.to(tdtype)
@@ -490,7 +492,8 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
                                        ("az_tower_f32.hip: k_tower_f32_t16<QuickModel> (f32 MFMA conv tower, 16-cell tiles, 3x3 head convs) + k_quick_heads_f32"
                                         if dtype_name == "f32" else "az_tower.hip: k_tower<QuickModel> (fused bf16 MFMA conv tower, 3x3 head convs) + k_quick_heads")
                                        if "layers" in WORKLOADS[args.workload][4] else
-                                       "az_tower_f32.hip: k_tower_f32_t16 (f32 MFMA conv tower, 16-cell tiles) + k_heads_f32" if dtype_name == "f32" else
+                                       "az_tower_f32.hip: k_tower_f32_t16 (f32 MFMA conv tower, direct convolution, 16-cell tiles) + k_heads_f32" if dtype_name == "f32" else
+                                       "az_tower_w.hip: k_tower_f32w (f32 MFMA conv tower, 3x3 convolutions by the Winograd transform F(2x2,3x3)) + k_heads_f32" if dtype_name == "f32w" else
                                        "az_tower_h2.hip: k_tower_h2 (f32 operands as two f16 halves, three f16 MFMAs per product, f32 accumulation) + k_heads_f32" if h2 else
                                        f"az_tower_h1.hip: k_tower_h1 (row-tile conv tower, {'f16' if dtype_name == 'f16r' else 'bf16'} MFMA, f32 accumulation) + k_heads_f32" if named_tower else
                                        "az_tower.hip: k_tower (fused bf16 MFMA conv tower) + k_heads (MFMA head linears)")
@@ -508,6 +511,16 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
                         "unit": "TFLOP/s", "frac": tw_fl / (tw_ms * 1e-3) / 1e12 / peak, "traffic": ttraffic,
                         "traffic_note": tnote, "flops_per_launch": tw_fl, "boards_per_launch": evals_per_launch,
                         "ms_per_launch": tw_ms, "share_of_step": tw_ms / max(nn_ms + tree_ms, 1e-9)}
+            if dtype_name == "f32w":
+                # what the MFMA pipe executes: 16 transform points x 64 tiles of 2x2 outputs x 64 x 64 (stem: 16 of the padded input
+                # channels) multiply-adds per layer = (4 + 16 L) k-steps x 256 MFMAs of 2,048 flops per board
+                n_l = sum(1 for m in model.modules() if isinstance(m, tnn.Conv2d) and m.kernel_size == (3, 3)) - 1
+                ex_fl = (4 + 16 * n_l) * 256 * 2048.0 * evals_per_launch
+                net_roofline["executed"] = {"flops_per_launch": ex_fl, "achieved": ex_fl / (tw_ms * 1e-3) / 1e12, "frac": ex_fl / (tw_ms * 1e-3) / 1e12 / peak}
+                net_roofline["note"] = ("achieved / frac price the ALGORITHMIC flops of the network (the direct 3x3 convolutions' multiply-adds x 2, as for "
+                                        "every other tower) against the f32 MFMA peak; the kernel computes them by the Winograd transform F(2x2,3x3) in f32, "
+                                        "which executes 2.1x fewer multiply-adds, so frac may exceed 1; 'executed' = the MFMA flops really issued "
+                                        "(the pipe's utilisation; the rest of the time goes to the transforms' VALU adds, which cannot co-execute with f32 MFMAs)")
             if h2:
                 net_roofline["f32_equivalent_tflops"] = f32_equiv
                 net_roofline["note"] = ("achieved / peak count the f16 MFMA flops executed (3 per multiply-add of the convolution: w1 x1 + w1 x2 + "
@@ -522,7 +535,7 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
         "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"bf16r": "bf16", "f16r": "f16"}.get(dtype_name, dtype_name), "data": "synthetic",
+        "dtype": {"bf16r": "bf16", "f16r": "f16", "f32w": "f32"}.get(dtype_name, dtype_name), "data": "synthetic",
         "config": {"workload": f"{args.workload}: {sims} sims/move, {slots} concurrent games per GPU, "
                                f"evaluator={evaluator} ({dtype_name} network arithmetic), one step = one self-play move of every game",
                    "slots_per_gpu": slots, "sims_per_move": sims, "parallelism": f"games sharded x{world}, no data-path collective",
@@ -569,7 +582,7 @@ def decision_agreement(args, dev, n_pos=1024, plies=12, other="bf16"):
     torch.cuda.manual_seed(99)
     res, pos_moves = {}, None
     noise = expo = None
-    named = {"f16x2": "f16x2", "f16r": "f16", "bf16r": "bf16r"}  # towers asked for by name on an f32 engine
+    named = {"f32": "f32", "f32w": "f32w", "f16x2": "f16x2", "f16r": "f16", "bf16r": "bf16r"}  # towers asked for by name on an f32 engine
     for name, dt in (("f32", torch.float32), (other, torch.bfloat16 if other == "bf16" else torch.float32)):
         model = make_model(args.workload).to(dev).to(dt)
         eng = Engine(game, n_pos, sims, board_size=n, nn_dtype=dt, device=dev)
@@ -617,8 +630,8 @@ def decision_agreement(args, dev, n_pos=1024, plies=12, other="bf16"):
             "same_sampled_move": float((s32 == s16)[live].sum()) / nl,
             "identical_visit_vectors": float((v32 == v16).all(1)[live].sum()) / nl,
             "mean_abs_pi_difference": float(((v32.float() - v16.float()).abs().sum(1) / max(sims - 1, 1))[live].mean()) / 2,
-            "how": f"{nl} positions {plies} plies into a game, same Dirichlet and exponential rows, full search with the f32 tower "
-                   f"(az_tower_f32.hip) and with the {other} tower ({'az_tower.hip' if other == 'bf16' else 'az_tower_h2.hip' if other == 'f16x2' else 'az_tower_h1.hip'}); mean_abs_pi_difference = total variation "
+            "how": f"{nl} positions {plies} plies into a game, same Dirichlet and exponential rows, full search with the direct-convolution f32 tower "
+                   f"(az_tower_f32.hip) and with the {other} tower ({'az_tower.hip' if other == 'bf16' else 'az_tower_h2.hip' if other == 'f16x2' else 'az_tower_w.hip' if other == 'f32w' else 'az_tower_h1.hip'}); mean_abs_pi_difference = total variation "
                    "distance between the two root visit distributions"}
 
 
@@ -821,18 +834,25 @@ def main():
 
     primary = args.dtype
     if primary == "auto":
-        primary = "f32"  # the reference's own arithmetic; every workload has an f32 evaluator (hand-written tower or the module's forward)
+        # f32, the reference's own arithmetic; every workload has an f32 evaluator (hand-written tower or the module's forward).  The
+        # 15x15 / 64-channel GomokuModel network runs on the Winograd f32 tower (az_tower_w.hip: what SelfPlayRunner(fused=True) picks
+        # for it on an f32 engine); --dtype f32 asks for the direct-convolution f32 tower (az_tower_f32.hip) by name
+        primary = "f32w" if args.workload in ("gomoku15", "gomoku15_deep64") and args.evaluator in ("auto", "fused") else "f32"
     out = measure(args, primary, args.steps, args.warmup, dev, rank, world, dst)
+    f32_family = primary in ("f32", "f32w")
     sec_steps = args.secondary_steps if args.secondary_steps >= 0 else (min(args.steps, 4) if world == 1 else 0)
     second = second_f16 = None
     row_tile = False
-    if primary == "f32" and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1:
+    direct = None
+    if primary == "f32w" and sec_steps > 0 and args.leaves <= 1:  # the same workload on the direct-convolution f32 tower, for comparison
+        direct = measure(args, "f32", sec_steps, 1, dev, rank, world, dst, with_probe=False)
+    if f32_family and sec_steps > 0 and WORKLOADS[args.workload][0] == 2 and args.evaluator in ("auto", "fused") and args.leaves <= 1:
         # the 15x15 / 64-channel GomokuModel network: the row-tile tower (az_tower_h1.hip), bf16 operands like az_tower.hip's
         row_tile = args.workload in ("gomoku15", "gomoku15_deep64")
         second = measure(args, "bf16r" if row_tile else "bf16", sec_steps, 1, dev, rank, world, dst)
         second_f16 = measure(args, "f16r", sec_steps, 1, dev, rank, world, dst, with_probe=False) if row_tile else None
     third = None
-    if primary == "f32" and sec_steps > 0 and args.workload in ("gomoku15", "gomoku9", "gomoku15_deep64") and args.evaluator in ("auto", "fused") \
+    if f32_family and sec_steps > 0 and args.workload in ("gomoku15", "gomoku9", "gomoku15_deep64") and args.evaluator in ("auto", "fused") \
             and args.leaves <= 1:
         third = measure(args, "f16x2", sec_steps, 1, dev, rank, world, dst, with_probe=False)
     ranks_seen = dst.gather_objects({"rank": rank, "device": dev_index, "pid": os.getpid()}) if dst is not None else None
@@ -841,6 +861,19 @@ def main():
         if cpu:
             cpu["network_precision"] = "f32 (torch-CPU forward of the same network, as the reference runs it)"
             out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+        if primary == "f32w":
+            out["network_algorithm"] = ("f32 operands, products and sums (the reference's arithmetic type, nn_models/base.py:17-19); the 3x3 convolutions by the "
+                                        "Winograd transform F(2x2,3x3) on f32 MFMAs (az_tower_w.hip) -- the algorithm GPU libraries choose for f32 3x3 "
+                                        "convolutions; against an f64 evaluation of the network its logits are as close as the direct-convolution tower's "
+                                        "(tests/test_gpu_tower_w.py); f32_direct_mode = the same workload on the direct-convolution f32 tower")
+        if direct is not None:
+            rd = direct["roofline"]
+            out["f32_direct_mode"] = {
+                "value": direct["value"], "unit": "sims/s", "ms_per_step": direct["ms_per_step"], "dtype": "f32",
+                "roofline": {k: rd[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "ms_per_launch", "boards_per_launch")},
+                "note": "az_tower_f32.hip: the same f32 network by direct convolution (rounds 1-2's primary line)",
+                "speedup_of_primary": out["value"] / direct["value"],
+                "decision_agreement": None if args.no_agreement else decision_agreement(args, dev, other="f32w")}
         if second is not None:
             second["note"] = ("the same workload with the bf16 tower (bf16 operands, f32 accumulation): NOT the reference's precision; "
                               "decisions differ from the f32 search as measured in decision_agreement")

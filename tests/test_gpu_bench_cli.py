@@ -46,7 +46,15 @@ def test_bench_line_gomoku_f32_primary_with_bf16_beside_it_under_rccl():
 
 def test_bench_line_gomoku15_throughput_mode_is_the_row_tile_tower():
     d = _run(["--workload", "gomoku15", "--slots", "128", "--sims", "12", "--no-cpu-baseline"])
-    assert d["dtype"] == "f32" and d["roofline"]["kernel"] == "k_tower_f32_t16"
+    # the primary line: f32 arithmetic on the Winograd tower (az_tower_w.hip); its roofline prices the network's algorithmic
+    # (direct-convolution) flops and carries the executed MFMA flops beside them; the direct-convolution tower as a comparison object
+    assert d["dtype"] == "f32" and d["roofline"]["kernel"] == "k_tower_f32w" and "az_tower_w.hip" in d["nn_eval"]["implementation"]
+    assert 0 < d["roofline"]["executed"]["frac"] < 1 and d["roofline"]["executed"]["flops_per_launch"] < d["roofline"]["flops_per_launch"]
+    fd = d["f32_direct_mode"]
+    assert fd["dtype"] == "f32" and fd["roofline"]["kernel"] == "k_tower_f32_t16" and fd["value"] > 0
+    assert fd["decision_agreement"]["same_most_visited_move"] >= 0.9
+    dd = _run(["--workload", "gomoku15", "--slots", "128", "--sims", "12", "--no-cpu-baseline", "--dtype", "f32", "--secondary-steps", "0"])
+    assert dd["dtype"] == "f32" and dd["roofline"]["kernel"] == "k_tower_f32_t16" and "f32_direct_mode" not in dd
     t = d["throughput_mode"]
     assert t["dtype"] == "bf16" and t["roofline"]["kernel"] == "k_tower_h1" and "az_tower_h1.hip" in t["nn_eval"]["implementation"]
     assert t["decision_agreement"]["same_most_visited_move"] >= 0.5

@@ -98,11 +98,13 @@ def _tower_callback(ev, shape, dtype):
     return O.EVAL_FN(_cb), calls
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f32", "f32-quick", "bf16-quick", "f16x2", "bf16r", "f16"])
+@pytest.mark.parametrize("precision", ["bf16", "f32", "f32w", "f32-quick", "bf16-quick", "f16x2", "bf16r", "f16"])
 def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     """engine + tower on the packed/flags path == oracle + the same tower as its evaluator ("f32-quick": the reference's
     QuickModel family, 128 channels, on the f32 tower's QuickModel instantiation -- config 5's network; "f16x2": the
-    split-operand tower of az_tower_h2.hip on an f32 engine; "bf16r" / "f16": the row-tile tower of az_tower_h1.hip, likewise)"""
+    split-operand tower of az_tower_h2.hip on an f32 engine; "bf16r" / "f16": the row-tile tower of az_tower_h1.hip, likewise;
+    "f32w": the Winograd f32 tower of az_tower_w.hip -- what fused=True picks for this network on an f32 engine, the bench's primary line;
+    "f32": the direct-convolution f32 tower by name)"""
     from alphazero_amd import Engine
     from alphazero_amd.arena import SelfPlayRunner
     from alphazero_amd.nets import GomokuNet, QuickNet
@@ -118,7 +120,7 @@ def test_runner_search_fused_tower_matches_oracle(oracle, precision):
     for g, (h, p) in enumerate(pos):
         eng.set_position(g, h, p)
     # ("bf16" by name: az_tower.hip -- left to itself the runner picks the row-tile tower for this network on a bf16 engine)
-    run = SelfPlayRunner(eng, net, sims, fused=precision if precision in ("f16x2", "bf16r", "f16", "bf16") else True)
+    run = SelfPlayRunner(eng, net, sims, fused=precision if precision in ("f16x2", "bf16r", "f16", "bf16", "f32") else True)
     assert run.fused is not None and run.fused.precision == precision.split("-")[0]
     noise_np = rng.dirichlet([0.3] * A, size=G).astype(np.float32)
     _fix_noise(run, noise_np)
