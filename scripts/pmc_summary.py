@@ -27,7 +27,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         mean_kb = tot / max(n, 1)
         corr = 2.0 if counter == "FETCH_SIZE" else 1.0
         key = ("k_tower_h1_f16" if "k_tower_h1<azh1::F16>" in name else
-               next((k for k in ("k_expand_select", "k_select_gather", "k_expand_backup", "k_tower_f32_t16", "k_tower_f32", "k_tower_h1",
+               next((k for k in ("k_expand_select", "k_select_gather", "k_expand_backup", "k_tower_f32w", "k_tower_f32_t16", "k_tower_f32", "k_tower_h1",
                                  "k_tower_h2", "k_tower", "k_heads_f32", "k_heads") if k in name), name))
         summary.setdefault(key, {})[counter] = {"dispatches": n, "raw_bytes_per_launch": mean_kb * 1e3,
                                                 "corrected_bytes_per_launch": mean_kb * corr * 1e3, "correction": corr}
