@@ -405,6 +405,43 @@ def test_fused_kernel_selection_is_decided_from_the_module_alone():
     assert evaluator_available(2, nets.QuickNet(15, 9, 128, 1, 5), bf16) and not evaluator_available(2, nets.QuickNet(3, 9, 128, 1, 5, n_action=9), f32)
 
 
+def test_winograd_weight_packing_reproduces_the_convolution():
+    """fused._pack_winograd_f32 (the weights of csrc/az_tower_w.hip): unpacked through the kernel's own indexing -- stage, j, kq,
+    channel tile, point row, channel, point column -- and run through a plain restatement of F(2x2, 3x3) on the 8 x 8 tiles of a
+    15x15 board, U gives the same outputs as torch's conv2d on the original filters; the stem's padded input channels are zero;
+    and which networks the Winograd tower takes is decided from the module alone."""
+    import torch
+    import torch.nn.functional as Fn
+
+    from alphazero_amd import nets
+    from alphazero_amd.fused import FusedTowerEvaluator as F, _pack_winograd_f32
+
+    torch.manual_seed(5)
+    for ci, pad in ((64, 64), (9, 16)):
+        w = torch.randn(64, ci, 3, 3, dtype=torch.float32) * 0.1
+        packed = _pack_winograd_f32(w, pad)
+        assert tuple(packed.shape) == (pad // 8, 2, 4, 4, 4, 16, 4) and packed.dtype == torch.float32 and packed.is_contiguous()
+        # U[co][ci][i][q]: ci = 8 stage + 2 kq + j, co = 16 tile + c
+        u = packed.permute(3, 5, 0, 2, 1, 4, 6).reshape(64, pad, 4, 4).double()
+        assert float(u[:, ci:].abs().max()) == 0.0 if ci < pad else True
+        x = torch.randint(-1, 2, (2, ci, 15, 15)).double()
+        xp = Fn.pad(x, (1, 2, 1, 2))  # rows / columns -1 .. 16
+        bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+        at = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+        y = torch.zeros(2, 64, 16, 16, dtype=torch.float64)
+        for ty in range(8):
+            for tx in range(8):
+                d = xp[:, :, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]  # (B, ci, 4, 4)
+                v = bt @ d @ bt.t()
+                m = torch.einsum("ocij,bcij->boij", u[:, :ci], v)
+                y[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = at @ m @ at.t()
+        ref = Fn.conv2d(x, w.double(), padding=1)
+        assert float((y[:, :, :15, :15] - ref).abs().max()) < 1e-6
+    assert F.winograd_supports(nets.GomokuNet(15, 64, 2)) and F.winograd_supports(nets.GomokuNet(15, 64, 20))
+    assert not F.winograd_supports(nets.GomokuNet(15, 64, 21)) and not F.winograd_supports(nets.GomokuNet(9, 64, 2))
+    assert not F.winograd_supports(nets.GomokuNet(15, 128, 2)) and not F.winograd_supports(nets.QuickNet(15, 9, 64, 1, 2))
+
+
 def test_bench_launcher_starts_one_rank_per_gpu_before_any_gpu_call():
     """`python bench.py --gpus 2` with no launcher around it becomes the launcher: two children of the same script with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, started before torch is imported (--launch-dry-run returns there).
