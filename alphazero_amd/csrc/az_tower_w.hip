@@ -21,11 +21,14 @@
 //     fixed per lane: cells off the board point at a zero cell), forms V = B^T d B in registers (32 packed adds) and feeds 64
 //     MFMAs (16 points x 2 channel tiles x 2 k-steps) with it -- the transformed input never exists in memory;
 //   * the inverse transform A^T M A is in-lane too: the 16 M_p of an (output channel, tile) pair are 16 registers of one lane.
-// Transformed weights U (host: G g G^T in f64, rounded to f32; 256 KiB per layer) stream L2 -> LDS by LDS-DMA in stages of 8
-// input channels (32 KiB, double buffered, one barrier per stage), laid out so that a lane's A operands of four points are one
-// conflict-free ds_read_b128.  Bias and the block's residual enter through the accumulators: A^T M A maps
-// M[0][0], -M[0][3], -M[3][0], M[3][3] to the four outputs of the tile one to one, so the lane that overwrites a block's
-// input in the first conv's epilogue reads it there and starts the second conv's accumulators at bias + x (as az_tower_f32.hip).
+// Transformed weights U (host: G g G^T in f64, rounded to f32; 256 KiB per layer) stream L2 -> LDS by LDS-DMA in k-steps of 4
+// input channels (16 KiB) through four buffers, three k-steps ahead of their use and straight across layer and board boundaries
+// (one LDS-only barrier per k-step; conv_w), laid out so that a lane's A operands of four points are one conflict-free
+// ds_read_b128.  Bias and the block's residual enter through the accumulators: A^T M A maps M[0][0], -M[0][3], -M[3][0], M[3][3]
+// to the four outputs of the tile one to one, so the lane that overwrites a block's input in the first conv's epilogue reads it
+// there and starts the second conv's accumulators at bias + x (as az_tower_f32.hip); the other twelve accumulators of a tile start
+// from the first MFMA's zero operand.  What bounds the kernel (measured): f32 MFMAs and VALU instructions do not
+// co-execute, so the transforms' adds are MFMA time -- MFMA pipe busy 0.71, VALU 0.22.
 // Boards are handed out by the library's ticket counter (az_tower.hip); the input is the engine's packed leaf batch (8
 // bitboards + player) with its needs-the-network flags, or dense f32 planes.  Output: the f32 feature rows k_heads_f32 reads.
 // C ABI at the bottom; declared in include/az_engine.h.
@@ -53,7 +56,7 @@ constexpr int RSB = 4032;                     // bytes per board row (15 cells +
 constexpr int ZERO_OFF = N * RSB;             // a cell of zeros: every patch element off the board
 constexpr int DUMP_OFF = ZERO_OFF + CSB;      // where the outputs of the 16th row / column go
 constexpr int ACT_BYTES = (DUMP_OFF + CSB + 15) / 16 * 16;
-constexpr int STAGE_BYTES = 32768;            // U of 8 input channels: [j 2][kq 4][ct 4][pg 4][co 16][4 points] f32
+constexpr int STAGE_BYTES = 32768;            // U of 8 input channels (two k-steps): [j 2][kq 4][ct 4][pg 4][co 16][4 points] f32
 constexpr int KSTEP_BYTES = STAGE_BYTES / 2;  // one k-step (j): 4 input channels, one per 16-lane group kq
 constexpr int MAX_LAYERS = 40;                // bias rows kept in LDS
 constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = 8 * SWB;  // packed input: 8 states x 2 colours x 8 words
