@@ -182,7 +182,8 @@ def test_runner_search_graph_replay_matches_eager(oracle, kind):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("kind", ["gomokunet-f32", "quicknet-bf16", "dab-smallnet", "gomokunet15-rowtile-bf16", "gomokunet15-rowtile-f16"])
+@pytest.mark.parametrize("kind", ["gomokunet-f32", "quicknet-bf16", "dab-smallnet", "gomokunet15-rowtile-bf16", "gomokunet15-rowtile-f16",
+                                  "gomokunet15-winograd-f32"])
 def test_graph_replay_after_weight_refresh_matches_eager(oracle, kind):
     """A weight publish between two moves: ``refresh()`` re-folds the module's new weights into the evaluator's packed tensors.
     A search graph captured BEFORE the refresh has those tensors' addresses baked in, so the refresh must rewrite them in place
@@ -198,9 +199,11 @@ def test_graph_replay_after_weight_refresh_matches_eager(oracle, kind):
     if kind == "dab-smallnet":
         game, n, G, sims, dt = 1, 3, 64, 40, torch.float32
         mk = lambda: DotsAndBoxesNet()
-    elif "rowtile" in kind:  # az_tower_h1.hip under graph replay: its one-board-ahead hand-over, scales and selector fragments
+    elif "rowtile" in kind or "winograd" in kind:
+        # az_tower_h1.hip under graph replay: its one-board-ahead hand-over, scales and selector fragments; az_tower_w.hip (what
+        # fused=True picks for this network on an f32 engine): its weight stream running across board and layer boundaries
         game, n, G, sims, dt = 2, 15, 40, 30, torch.float32
-        fused = "bf16r" if kind.endswith("bf16") else "f16"
+        fused = True if "winograd" in kind else "bf16r" if kind.endswith("bf16") else "f16"
         mk = lambda: _randomised(GomokuNet(n, 64, 2))
     else:
         game, n, G, sims = 2, 9, 48, 40
@@ -229,6 +232,7 @@ def test_graph_replay_after_weight_refresh_matches_eager(oracle, kind):
 
     eng = fresh_engine()
     run = SelfPlayRunner(eng, net, sims, fused=fused, use_graph=True)
+    assert "winograd" not in kind or run.fused.precision == "f32w"
     _fix_noise(run, noise_np)
     run.search()  # captures the graph on the OLD weights
     old = _results(eng)
