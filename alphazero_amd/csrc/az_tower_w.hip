@@ -50,27 +50,39 @@ namespace aztw {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-constexpr int N = 15, NV = N * N, C = 64;
+constexpr int C = 64;
 constexpr int CSB = 264;                      // bytes per cell (64 f32 + 8)
-constexpr int RSB = 4032;                     // bytes per board row (15 cells + 72)
-constexpr int ZERO_OFF = N * RSB;             // a cell of zeros: every patch element off the board
-constexpr int DUMP_OFF = ZERO_OFF + CSB;      // where the outputs of the 16th row / column go
-constexpr int ACT_BYTES = (DUMP_OFF + CSB + 15) / 16 * 16;
 constexpr int STAGE_BYTES = 32768;            // U of 8 input channels (two k-steps): [j 2][kq 4][ct 4][pg 4][co 16][4 points] f32
 constexpr int KSTEP_BYTES = STAGE_BYTES / 2;  // one k-step (j): 4 input channels, one per 16-lane group kq
 constexpr int MAX_LAYERS = 40;                // bias rows kept in LDS
-constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = 8 * SWB;  // packed input: 8 states x 2 colours x 8 words
 constexpr int NTH = 512;
-
 constexpr int OFF_ACT = 2 * STAGE_BYTES;
-constexpr int OFF_BL = OFF_ACT + ACT_BYTES;
-constexpr int OFF_HW = OFF_BL + (1 + MAX_LAYERS) * C * 4;
-constexpr int OFF_HP = OFF_HW + 208 * 4;                       // 3 x 64 head filters + 3 biases (+ pad)
-constexpr int OFF_RG = OFF_HP + ((2 * 3 * NV + 3) / 4 * 4) * 4;  // [2 channel halves][3 heads][NV] partial head sums
-constexpr int OFF_SL = OFF_RG + (RGW + 4) * 4;
-constexpr int LDS_BYTES = OFF_SL + 8 * 4;
-static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-static_assert(OFF_BL % 16 == 0 && OFF_HW % 16 == 0 && OFF_HP % 16 == 0 && OFF_RG % 16 == 0, "alignment");
+
+// Board geometry.  15x15: 8 x 8 tiles = four groups of 16, one board per workgroup.  9x9: 5 x 5 tiles = two groups (16 + 9 tiles,
+// seven idle lanes), TWO boards per workgroup (wave w: board (w & 3) / 2); a ticket then stands for a pair of boards.
+template <int N>
+struct Geo {
+  static constexpr int NV = N * N, TR = (N + 1) / 2, NT = TR * TR, GPB = (NT + 15) / 16, BPW = 4 / GPB;
+  static_assert(GPB * BPW == 4, "the four tile groups of a workgroup");
+  // bytes per board row: 15 cells + 72 / 9 cells + 96 -- with CSB = 33 and RSB = 504 / 309 units of 8 B, tile (ty, tx) sits at
+  // 2 (ty RSB + tx CSB): 8 ty + tx / 5 ty + tx modulo 16 is different for the 16 tiles of a group (bank pairs of a ds_read_b64)
+  static constexpr int RSB = N == 15 ? 4032 : 2472;
+  static constexpr int BOARD_BYTES = N * RSB;
+  static constexpr int ZERO_OFF = BPW * BOARD_BYTES;         // a cell of zeros: every patch element off the board
+  static constexpr int DUMP_OFF = ZERO_OFF + CSB;            // where the outputs of cells that do not exist go
+  static constexpr int ACT_BYTES = (DUMP_OFF + CSB + 15) / 16 * 16;
+  static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = 8 * SWB;  // packed input: 8 states x 2 colours x WC words
+  static constexpr int RGS = RGW + 4;                        // words per board in the input buffer (ring words, the player word, pad)
+  static constexpr int OFF_BL = OFF_ACT + ACT_BYTES;
+  static constexpr int OFF_HW = OFF_BL + (1 + MAX_LAYERS) * C * 4;
+  static constexpr int OFF_HP = OFF_HW + 208 * 4;            // 3 x 64 head filters + 3 biases (+ pad)
+  static constexpr int OFF_RG = OFF_HP + ((BPW * 2 * 3 * NV + 3) / 4 * 4) * 4;  // [board][2 channel halves][3 heads][NV] partial head sums
+  static constexpr int OFF_SL = OFF_RG + BPW * RGS * 4;
+  static constexpr int LDS_BYTES = OFF_SL + 8 * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+  static_assert(OFF_BL % 16 == 0 && OFF_HW % 16 == 0 && OFF_HP % 16 == 0 && OFF_RG % 16 == 0, "alignment");
+  static_assert(BPW * 2 * NV <= NTH && BPW * NV <= NTH && BPW * (RGW + 1) <= NTH, "one pass of the workgroup per phase");
+};
 
 #ifndef AZ_W_ABLATE
 #define AZ_W_ABLATE 0  // diagnostic builds (wrong results, timing only): 1 no patch reads / input transform, 2 no stage barriers,
@@ -208,24 +220,29 @@ __device__ __forceinline__ void conv_w(uint32_t lds0, const uint32_t (&pa)[16], 
   }
 }
 
+template <int N>
 __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__ x, const uint32_t *__restrict__ ring,
                                                         const int4 *__restrict__ leafrec, const uint8_t *__restrict__ flags, int G,
                                                         const char *__restrict__ u0, const char *__restrict__ ul,
                                                         const float *__restrict__ bias, int L, const float *__restrict__ headw,
                                                         const float *__restrict__ headb, float *__restrict__ feat, int FS,
                                                         unsigned int *tickets) {
+  using Q = Geo<N>;
+  constexpr int NV = Q::NV, TR = Q::TR, NT = Q::NT, GPB = Q::GPB, BPW = Q::BPW, RSB = Q::RSB, BOARD_BYTES = Q::BOARD_BYTES;
+  constexpr int ZERO_OFF = Q::ZERO_OFF, DUMP_OFF = Q::DUMP_OFF, ACT_BYTES = Q::ACT_BYTES, WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RGS = Q::RGS;
   extern __shared__ __attribute__((aligned(1024))) char smem_w[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem_w;
   const uint32_t act0 = lds0 + OFF_ACT;
   char *act = smem_w + OFF_ACT;
-  float *bl = (float *)(smem_w + OFF_BL);
-  float *hw = (float *)(smem_w + OFF_HW);
-  float *hp = (float *)(smem_w + OFF_HP);
-  uint32_t *rg = (uint32_t *)(smem_w + OFF_RG);
-  int *slots = (int *)(smem_w + OFF_SL);  // {this board, the next ticket, its flag byte (-1: not read)}
+  float *bl = (float *)(smem_w + Q::OFF_BL);
+  float *hw = (float *)(smem_w + Q::OFF_HW);
+  float *hp = (float *)(smem_w + Q::OFF_HP);
+  uint32_t *rgb = (uint32_t *)(smem_w + Q::OFF_RG);
+  int *slots = (int *)(smem_w + Q::OFF_SL);  // {this ticket (group of BPW boards), the next ticket, its flag (-1: not read), -, 4 + b: board b is evaluated}
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, kq = lane >> 4, tg = wave & 3, chalf = wave >> 2;
-  const int ty = 2 * tg + (n >> 3), tx = n & 7;
+  const int n = lane & 15, kq = lane >> 4, chalf = wave >> 2;
+  const int wb = (wave & 3) / GPB, tg = (wave & 3) % GPB;  // the wave's board of the workgroup and tile group of that board
+  const int tile = 16 * tg + n, ty = tile / TR, tx = tile - ty * TR;  // (tile >= NT: an idle lane -- reads zeros, writes to the dump cell)
 
   for (int i = tid; i < ACT_BYTES / 16; i += NTH) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero and dump cells
   for (int i = tid; i < (1 + L) * C; i += NTH) bl[i] = bias[i];
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = 2 * ty - 1 + (i >> 2), c = 2 * tx - 1 + (i & 3);
-    pa[i] = act0 + (uint32_t)((r >= 0 && r < N && c >= 0 && c < N ? r * RSB + c * CSB : ZERO_OFF) + kq * 8);
+    pa[i] = act0 + (uint32_t)((tile < NT && r >= 0 && r < N && c >= 0 && c < N ? wb * BOARD_BYTES + r * RSB + c * CSB : ZERO_OFF) + kq * 8);
   }
   // Everything the epilogues need per lane (its output cells, its channels) is re-derived from a laundered copy of the lane index
   // inside each epilogue: hoisted out of the board loop these values would sit in registers through the conv loops, which run
@@ -262,13 +279,13 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
   // inverse transform, ReLU, store in place; the next layer's accumulators start at its bias (+ the activations this lane
   // overwrites, when they are the residual of the block's second conv)
   auto epilogue = [&](bool with_res, const float *bnext) {
-    const int ln = fresh(lane), n_ = ln & 15, kq_ = ln >> 4, ty_ = 2 * tg + (n_ >> 3), tx_ = n_ & 7;
+    const int ln = fresh(lane), tile_ = 16 * tg + (ln & 15), kq_ = ln >> 4, ty_ = tile_ / TR, tx_ = tile_ - ty_ * TR;
     const int bo = 32 * chalf + 4 * kq_;  // first of the lane's channels (ct adds 16)
     uint32_t oc[4];                        // the lane's 2x2 outputs
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 2 * ty_ + (i >> 1), c = 2 * tx_ + (i & 1);
-      oc[i] = act0 + (uint32_t)((r < N && c < N ? r * RSB + c * CSB : DUMP_OFF) + bo * 4);
+      oc[i] = act0 + (uint32_t)((tile_ < NT && r < N && c < N ? wb * BOARD_BYTES + r * RSB + c * CSB : DUMP_OFF) + bo * 4);
     }
     f32x4 y[4][2];  // [output 2 a + b][ct] (4 channels r)
 #pragma unroll
@@ -313,45 +330,61 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     ++it;
 #endif
     WSTAMP(0);
-    if (tid == 0) {  // this board: the ticket drawn ahead, or -- when its leaf is terminal (flag off) -- the next that is not
+    if (tid == 0) {  // this ticket: the one drawn ahead, or -- when none of its leaves needs the network (flags off) -- the next that does
       int tk = slots[1], fl = slots[2];
-      while (tk < G && flags != nullptr) {
-        if (fl < 0) fl = (int)flags[tk];
+      constexpr int NGdiv = BPW;
+      const int NG = (G + NGdiv - 1) / NGdiv;
+      while (tk < NG && flags != nullptr) {
+        if (fl < 0) {
+          fl = 0;
+#pragma unroll
+          for (int b = 0; b < BPW; ++b) fl |= tk * BPW + b < G ? (int)flags[tk * BPW + b] : 0;
+        }
         if (fl != 0) break;
         tk = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));
         fl = -1;
       }
       slots[0] = tk;
+#pragma unroll
+      for (int b = 0; b < BPW; ++b)
+        slots[4 + b] = tk < NG && tk * BPW + b < G && (flags == nullptr || flags[tk * BPW + b] != 0) ? 1 : 0;
     }
     __syncthreads();
-    const int g = slots[0];
-    if (g >= G) break;
+    const int gt = slots[0];
+    if (gt >= (G + BPW - 1) / BPW) break;
+    const int g = gt * BPW;  // the ticket's first board
     WSTAMP(1);
     unsigned int drawn = 0;
     if (tid == 0) drawn = atomicAdd(&tickets[0], 1u);  // the next ticket (lands while the input is fetched)
     if (x == nullptr) {
-      for (int i = tid; i < RGW + 1; i += NTH) rg[i] = i < RGW ? ring[(size_t)g * RGW + i] : (uint32_t)leafrec[g].w;
+      if (tid < BPW * (RGW + 1)) {
+        const int b = BPW == 1 ? 0 : tid / (RGW + 1), i = tid - b * (RGW + 1);
+        if (slots[4 + b] != 0) rgb[b * RGS + i] = i < RGW ? ring[(size_t)(g + b) * RGW + i] : (uint32_t)leafrec[g + b].w;
+      }
       __syncthreads();
     }
-    if (tid < NV) {
-      const int cell = tid, row = cell / N, col = cell - row * N;
-      float c[16];
+    if (tid < BPW * NV) {
+      const int b = BPW == 1 ? 0 : tid / NV, cell = tid - b * NV, row = cell / N, col = cell - row * N;
+      if (slots[4 + b] != 0) {  // (a board that is not evaluated keeps whatever its region holds: finite values, results discarded)
+        const uint32_t *rg = rgb + b * RGS;
+        float c[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) c[k] = 0.0f;
-      if (x != nullptr) {
-        const float *xr = x + (size_t)g * 9 * NV + cell;
+        for (int k = 0; k < 16; ++k) c[k] = 0.0f;
+        if (x != nullptr) {
+          const float *xr = x + (size_t)(g + b) * 9 * NV + cell;
 #pragma unroll
-        for (int cc = 0; cc < 9; ++cc) c[cc] = xr[cc * NV];
-      } else {
-        const int wi = cell >> 5, sh = cell & 31;
+          for (int cc = 0; cc < 9; ++cc) c[cc] = xr[cc * NV];
+        } else {
+          const int wi = cell >> 5, sh = cell & 31;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          c[k] = (float)(int)((rg[k * SWB + wi] >> sh) & 1u) - (float)(int)((rg[k * SWB + WC + wi] >> sh) & 1u);
-        c[8] = (int)rg[RGW] > 0 ? 1.0f : -1.0f;
+          for (int k = 0; k < 8; ++k)
+            c[k] = (float)(int)((rg[k * SWB + wi] >> sh) & 1u) - (float)(int)((rg[k * SWB + WC + wi] >> sh) & 1u);
+          c[8] = (int)rg[RGW] > 0 ? 1.0f : -1.0f;
+        }
+        const uint32_t a = act0 + (uint32_t)(b * BOARD_BYTES + row * RSB + col * CSB);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds_w2(a + 8 * k, (f32x2){c[2 * k], c[2 * k + 1]});
       }
-      const uint32_t a = act0 + (uint32_t)(row * RSB + col * CSB);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) lds_w2(a + 8 * k, (f32x2){c[2 * k], c[2 * k + 1]});
     }
     if (tid == 0) {
       slots[1] = (int)(gridDim.x + drawn);
@@ -393,9 +426,10 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     __syncthreads();
     WSTAMP(28);
     // ---- heads: the three 1x1 convs + ReLU from the finished activations: a thread takes a cell and half of its channels
-    for (int e = tid; e < 2 * NV; e += NTH) {
+    if (tid < BPW * 2 * NV) {
+      const int b = BPW == 1 ? 0 : tid / (2 * NV), e = tid - b * 2 * NV;
       const int half = e >= NV ? 1 : 0, cell = e - half * NV, row = cell / N, col = cell - row * N;
-      const uint32_t a = act0 + (uint32_t)(row * RSB + col * CSB + half * 128);
+      const uint32_t a = act0 + (uint32_t)(b * BOARD_BYTES + row * RSB + col * CSB + half * 128);
       const float *w = hw + half * 32;
       float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -408,20 +442,23 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
           s2 = fmaf(v[j], w[2 * C + 2 * k + j], s2);
         }
       }
-      hp[(half * 3 + 0) * NV + cell] = s0;
-      hp[(half * 3 + 1) * NV + cell] = s1;
-      hp[(half * 3 + 2) * NV + cell] = s2;
+      float *hb = hp + b * 6 * NV;
+      hb[(half * 3 + 0) * NV + cell] = s0;
+      hb[(half * 3 + 1) * NV + cell] = s1;
+      hb[(half * 3 + 2) * NV + cell] = s2;
     }
     WSTAMP(29);
     __syncthreads();
     WSTAMP(30);
     // feature rows [policy NV | pad to 16 | value0 NV | value1 NV | pad]: whole-wave consecutive 4-byte stores
     constexpr int KP = (NV + 15) / 16 * 16;
-    float *fr = feat + (size_t)g * FS;
-    for (int e = tid; e < 3 * NV; e += NTH) {
+    for (int e0 = tid; e0 < BPW * 3 * NV; e0 += NTH) {
+      const int b = BPW == 1 ? 0 : e0 / (3 * NV), e = e0 - b * 3 * NV;
       const int k = e / NV, cell = e - k * NV;
-      const float v = hp[k * NV + cell] + hp[(3 + k) * NV + cell];
-      fr[(k == 0 ? 0 : KP + (k - 1) * NV) + cell] = fmaxf(v + hw[3 * C + k], 0.0f);
+      if (slots[4 + b] == 0) continue;
+      const float *hb = hp + b * 6 * NV;
+      const float v = hb[k * NV + cell] + hb[(3 + k) * NV + cell];
+      feat[(size_t)(g + b) * FS + (k == 0 ? 0 : KP + (k - 1) * NV) + cell] = fmaxf(v + hw[3 * C + k], 0.0f);
     }
     // (the next board's first barriers order these reads of hp / act before anything overwrites them)
     WSTAMP(31);
@@ -443,7 +480,7 @@ extern "C" int az_debug_w_stamps(unsigned long long *out_host) {
 #endif
 
 static std::mutex g_w_mutex;
-static bool g_w_attr_done[64];
+static unsigned int g_w_attr_done[64];
 
 extern "C" int az_tower_forward_f32w(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const float *x_f32_dev,
                                      const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev, const void *u0_dev,
@@ -456,7 +493,7 @@ extern "C" int az_tower_forward_f32w(int32_t board_size, int32_t channels, int32
     tower_set_error("Winograd f32 tower: n_boards >= 1, an even number of conv layers, at most 40");
     return AZ_EINVAL;
   }
-  if (board_size != 15 || channels != 64) { tower_set_error("Winograd f32 tower: 15x15 boards, 64 channels"); return AZ_EINVAL; }
+  if ((board_size != 15 && board_size != 9) || channels != 64) { tower_set_error("Winograd f32 tower: 9x9 or 15x15 boards, 64 channels"); return AZ_EINVAL; }
   if (feat_stride < az_heads_feat_stride(board_size)) { tower_set_error("feat_stride below az_heads_feat_stride(board_size)"); return AZ_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   int dev = 0, cur = 0;
@@ -469,21 +506,27 @@ extern "C" int az_tower_forward_f32w(int32_t board_size, int32_t channels, int32
   } guard(dev, cur);
   unsigned int *tickets = tower_tickets(dev, s);
   if (tickets == nullptr) return AZ_EHIP;
-  {
-    std::lock_guard<std::mutex> lock(g_w_mutex);
-    if (!g_w_attr_done[dev]) {
-      if (hipFuncSetAttribute((const void *)k_tower_f32w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) {
-        tower_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-        return AZ_EHIP;
-      }
-      g_w_attr_done[dev] = true;
-    }
-  }
-  const int grid = n_boards < 256 ? n_boards : 256;  // one workgroup per CU (144 KiB of LDS each)
   const bool use_flags = !x_f32_dev && flags_dev;
-  hipLaunchKernelGGL(k_tower_f32w, dim3(grid), dim3(NTH), LDS_BYTES, s, x_f32_dev, (const uint32_t *)packed_ring_dev,
-                     (const int4 *)packed_leaf_dev, (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)u0_dev,
-                     (const char *)ul_dev, bias_dev, n_conv_layers, headw_dev, headb_dev, feat_f32_dev, (int)feat_stride, tickets);
+  auto launch = [&](auto kern, int lds, int bpw, unsigned int variant) -> int {
+    {
+      std::lock_guard<std::mutex> lock(g_w_mutex);
+      if (!(g_w_attr_done[dev] & variant)) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+          tower_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+          return AZ_EHIP;
+        }
+        g_w_attr_done[dev] |= variant;
+      }
+    }
+    const int groups = (n_boards + bpw - 1) / bpw, grid = groups < 256 ? groups : 256;  // one workgroup per CU (its LDS: 125 - 141 KiB)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, s, x_f32_dev, (const uint32_t *)packed_ring_dev, (const int4 *)packed_leaf_dev,
+                       (const uint8_t *)(use_flags ? flags_dev : nullptr), n_boards, (const char *)u0_dev, (const char *)ul_dev, bias_dev,
+                       n_conv_layers, headw_dev, headb_dev, feat_f32_dev, (int)feat_stride, tickets);
+    return AZ_OK;
+  };
+  const int rc = board_size == 15 ? launch(k_tower_f32w<15>, Geo<15>::LDS_BYTES, Geo<15>::BPW, 1u)
+                                  : launch(k_tower_f32w<9>, Geo<9>::LDS_BYTES, Geo<9>::BPW, 2u);
+  if (rc != AZ_OK) return rc;
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) { tower_set_error(std::string("k_tower_f32w launch: ") + hipGetErrorString(err)); return AZ_EHIP; }
   return AZ_OK;

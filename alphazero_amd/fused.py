@@ -236,8 +236,9 @@ class FusedTowerEvaluator:
 
     @classmethod
     def winograd_supports(cls, model: nn.Module) -> bool:
-        """the Winograd f32 tower (csrc/az_tower_w.hip; precision "f32w"): 64-channel GomokuModel family on 15x15, <= 40 conv layers"""
-        return cls.row_tile_supports(model) and 2 * (len(model._shared_layers) - 3) <= 40
+        """the Winograd f32 tower (csrc/az_tower_w.hip; precision "f32w"): 64-channel GomokuModel family on 9x9 or 15x15, <= 40 conv layers"""
+        return (cls.supports(model) and cls.quick_shape(model) is None and model._shared_layers[0].out_channels == 64
+                and 2 * (len(model._shared_layers) - 3) <= 40)
 
     def __init__(self, model: nn.Module, precision: str = "bf16"):
         """precision: "bf16" (az_tower.hip: bf16 operands, f32 accumulation -- the throughput mode), "f32"
@@ -260,8 +261,8 @@ class FusedTowerEvaluator:
                                               or model._policy_head[4].in_features != 225):
             raise EngineError("FusedTowerEvaluator: the row-tile tower (f16 / bf16r) covers 64-channel GomokuModel-family networks on 15x15")
         if precision == "f32w" and not self.winograd_supports(model):
-            raise EngineError("FusedTowerEvaluator: the Winograd f32 tower (f32w) covers 64-channel GomokuModel-family networks on 15x15, "
-                              "at most 20 residual blocks")
+            raise EngineError("FusedTowerEvaluator: the Winograd f32 tower (f32w) covers 64-channel GomokuModel-family networks "
+                              "(9x9 or 15x15), at most 20 residual blocks")
         if self.quick is not None:
             self.board, self.ch, self.q_blocks, self.q_layers = self.quick
             self.n2 = self.board * self.board

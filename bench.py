@@ -512,10 +512,10 @@ def measure(args, dtype_name, steps, warmup, dev, rank, world, dst, with_probe=T
                         "traffic_note": tnote, "flops_per_launch": tw_fl, "boards_per_launch": evals_per_launch,
                         "ms_per_launch": tw_ms, "share_of_step": tw_ms / max(nn_ms + tree_ms, 1e-9)}
             if dtype_name == "f32w":
-                # what the MFMA pipe executes: 16 transform points x 64 tiles of 2x2 outputs x 64 x 64 (stem: 16 of the padded input
-                # channels) multiply-adds per layer = (4 + 16 L) k-steps x 256 MFMAs of 2,048 flops per board
+                # what the MFMA pipe executes: 16 transform points x 64 tiles of 2x2 outputs (9x9: 32 tile slots) x 64 x 64 (stem: 16 of the
+                # padded input channels) multiply-adds per layer = (4 + 16 L) k-steps x 256 (128) MFMAs of 2,048 flops per board
                 n_l = sum(1 for m in model.modules() if isinstance(m, tnn.Conv2d) and m.kernel_size == (3, 3)) - 1
-                ex_fl = (4 + 16 * n_l) * 256 * 2048.0 * evals_per_launch
+                ex_fl = (4 + 16 * n_l) * (256 if d.height == 15 else 128) * 2048.0 * evals_per_launch  # (9x9: two tile groups of 16 per board)
                 net_roofline["executed"] = {"flops_per_launch": ex_fl, "achieved": ex_fl / (tw_ms * 1e-3) / 1e12, "frac": ex_fl / (tw_ms * 1e-3) / 1e12 / peak}
                 net_roofline["note"] = ("achieved / frac price the ALGORITHMIC flops of the network (the direct 3x3 convolutions' multiply-adds x 2, as for "
                                         "every other tower) against the f32 MFMA peak; the kernel computes them by the Winograd transform F(2x2,3x3) in f32, "
@@ -835,9 +835,9 @@ def main():
     primary = args.dtype
     if primary == "auto":
         # f32, the reference's own arithmetic; every workload has an f32 evaluator (hand-written tower or the module's forward).  The
-        # 15x15 / 64-channel GomokuModel network runs on the Winograd f32 tower (az_tower_w.hip: what SelfPlayRunner(fused=True) picks
+        # 64-channel GomokuModel networks (15x15 and 9x9) run on the Winograd f32 tower (az_tower_w.hip: what SelfPlayRunner(fused=True) picks
         # for it on an f32 engine); --dtype f32 asks for the direct-convolution f32 tower (az_tower_f32.hip) by name
-        primary = "f32w" if args.workload in ("gomoku15", "gomoku15_deep64") and args.evaluator in ("auto", "fused") else "f32"
+        primary = "f32w" if args.workload in ("gomoku15", "gomoku15_deep64", "gomoku9") and args.evaluator in ("auto", "fused") else "f32"
     out = measure(args, primary, args.steps, args.warmup, dev, rank, world, dst)
     f32_family = primary in ("f32", "f32w")
     sec_steps = args.secondary_steps if args.secondary_steps >= 0 else (min(args.steps, 4) if world == 1 else 0)

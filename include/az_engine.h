@@ -266,7 +266,7 @@ int az_tower_forward_h1(int32_t board_size, int32_t channels, int32_t n_boards, 
                         const float *headw_dev, const float *headb_dev, void *feat_dev, int32_t feat_bf16, int32_t feat_stride,
                         int32_t *overflow_dev, void *stream);
 
-/* Winograd f32 tower (csrc/az_tower_w.hip): the 15x15, 64-channel GomokuModel-family trunk (the network az_tower_forward_f32
+/* Winograd f32 tower (csrc/az_tower_w.hip): the 64-channel GomokuModel-family trunk on 15x15 or 9x9 boards (the network az_tower_forward_f32
  * evaluates; model contract nn_models/base.py:17-19, examples/gomoku/model.py:41-90) in plain f32 arithmetic -- f32 operands,
  * f32 products and sums on v_mfma_f32_16x16x4_f32 -- with the 3x3 convolutions computed by the Winograd transform F(2x2, 3x3)
  * (the algorithm cuDNN / MIOpen choose for f32 3x3 convolutions): 2.1x fewer MFMAs than the direct convolution of
@@ -276,7 +276,7 @@ int az_tower_forward_h1(int32_t board_size, int32_t channels, int32_t n_boards, 
  *   u0_dev [stage 2][j 2][kq 4][co tile 4][i 4][co 16][q 4] f32 (input channel 8 stage + 2 kq + j, 9 of 16 used; transform
  *   point (i, q); output channel 16 tile + co), ul_dev [n_conv_layers][stage 8][...] likewise;
  *   bias_dev [1 + n_conv_layers][64], headw_dev (3, 64), headb_dev (3) f32 as az_tower_forward_f32.
- * board_size 15, channels 64, n_conv_layers even, <= 40. */
+ * board_size 15 or 9 (two boards per workgroup), channels 64, n_conv_layers even, <= 40. */
 int az_tower_forward_f32w(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const float *x_f32_dev,
                           const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev, const void *u0_dev,
                           const void *ul_dev, const float *bias_dev, const float *headw_dev, const float *headb_dev,

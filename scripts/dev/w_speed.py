@@ -1,5 +1,5 @@
 """Launch time of the Winograd f32 tower (az_tower_w.hip) beside the direct f32 tower on dense batches:
-   python scripts/dev/w_speed.py [boards] [blocks]"""
+   python scripts/dev/w_speed.py [boards] [blocks] [board size]"""
 import os
 import sys
 
@@ -14,10 +14,11 @@ if __name__ == "__main__":
 
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
     blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 15
     torch.manual_seed(0)
-    net = GomokuNet(15, 64, blocks).eval().cuda()
-    x = torch.randint(-1, 2, (B, 9, 15, 15), device="cuda").float()
-    flops = B * 225 * 2.0 * 9 * (9 * 64 + 2 * blocks * 64 * 64)
+    net = GomokuNet(n, 64, blocks).eval().cuda()
+    x = torch.randint(-1, 2, (B, 9, n, n), device="cuda").float()
+    flops = B * n * n * 2.0 * 9 * (9 * 64 + 2 * blocks * 64 * 64)
     for prec in ("f32w", "f32"):
         ev = FusedTowerEvaluator(net, prec)
         xx = x.contiguous()
@@ -30,7 +31,7 @@ if __name__ == "__main__":
             ev(xx)
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in ev.kernel_events)[len(ev.kernel_events) // 2]
-        print(f"{prec}: {ms:.3f} ms per {B} boards = {flops / ms / 1e9:.0f} TFLOP/s of direct-convolution flops", flush=True)
+        print(f"{prec}: {ms:.3f} ms per {B} boards of {n}x{n} = {flops / ms / 1e9:.0f} TFLOP/s of direct-convolution flops", flush=True)
     import ctypes as C
 
     from alphazero_amd.engine import load_library

@@ -31,7 +31,9 @@ def test_bench_line_gomoku_f32_primary_with_bf16_beside_it_under_rccl():
     assert d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["kernel"] == "k_tower_f32_t16" and r["peak"] == 157.3 and 0 < r["frac"] < 1
+    # (the Winograd f32 tower: frac prices the network's algorithmic flops and may exceed 1; the executed MFMA flops sit beside it)
+    assert r["bound"] == "mfma" and r["kernel"] == "k_tower_f32w" and r["peak"] == 157.3 and r["frac"] > 0 and 0 < r["executed"]["frac"] < 1
+    assert d["f32_direct_mode"]["roofline"]["kernel"] == "k_tower_f32_t16" and 0 < d["f32_direct_mode"]["roofline"]["frac"] < 1
     assert d["roofline_tree"]["bound"] == "hbm" and d["roofline_tree"]["peak"] == 8000.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c

@@ -1,4 +1,4 @@
-"""az_tower_w.hip ("f32w"): the 15x15 / 64-channel GomokuModel-family tower in f32 arithmetic with the 3x3 convolutions computed
+"""az_tower_w.hip ("f32w"): the 64-channel GomokuModel-family tower (15x15, and 9x9 with two boards per workgroup) in f32 arithmetic with the 3x3 convolutions computed
 by the Winograd transform F(2x2, 3x3) (2.1x fewer MFMAs than the direct convolution of az_tower_f32.hip).  Plain f32 operands,
 products and sums, as the reference evaluates its network (nn_models/base.py:17-19); another summation order than the direct
 tower, so held -- like it -- to the f32 bars of tests/test_gpu_tower.py against an f64 evaluation of the same network: logits
@@ -12,16 +12,17 @@ from .test_gpu_tower import _randomised
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("blocks,batch", [(2, 64), (2, 1100), (3, 33), (0, 5), (1, 1), (10, 600), (2, 16384)])
-def test_winograd_tower_meets_the_f32_towers_accuracy_bars(blocks, batch):
+@pytest.mark.parametrize("board,blocks,batch", [(15, 2, 64), (15, 2, 1100), (15, 3, 33), (15, 0, 5), (15, 1, 1), (15, 10, 600), (15, 2, 16384),
+                                                (9, 2, 100), (9, 1, 7), (9, 0, 4), (9, 2, 1), (9, 6, 51), (9, 2, 4096)])
+def test_winograd_tower_meets_the_f32_towers_accuracy_bars(board, blocks, batch):
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import GomokuNet
 
     torch.manual_seed(0)
-    net = _randomised(GomokuNet(15, 64, blocks)).eval().cuda()
+    net = _randomised(GomokuNet(board, 64, blocks)).eval().cuda()
     ev = FusedTowerEvaluator(net, "f32w")
     ev32 = FusedTowerEvaluator(net, "f32")
-    x = torch.randint(-1, 2, (batch, 9, 15, 15), device="cuda").float()
+    x = torch.randint(-1, 2, (batch, 9, board, board), device="cuda").float()
     x[:, 8] = torch.where(torch.rand(batch, 1, 1, device="cuda") < 0.5, -1.0, 1.0)
     torch.backends.cudnn.allow_tf32 = False
     with torch.inference_mode():
@@ -44,14 +45,15 @@ def test_winograd_tower_meets_the_f32_towers_accuracy_bars(blocks, batch):
     assert torch.equal(p2, p[perm]) and torch.equal(v2, v[perm])
 
 
-def test_winograd_tower_packed_flags_equals_dense():
+@pytest.mark.parametrize("n,G", [(15, 2100), (9, 5301)])
+def test_winograd_tower_packed_flags_equals_dense(n, G):
     """the engine's packed leaf batch + needs-the-network flags == the dense planes of the same positions, bit for bit, for every
-    flag pattern (rows that are off keep their old contents)"""
+    flag pattern (9x9: an odd number of boards, so the last ticket is half a pair; pairs with one board flagged off)"""
     from alphazero_amd import Engine
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import GomokuNet
 
-    n, blocks, G = 15, 2, 2100
+    blocks = 2
     torch.manual_seed(3)
     net = _randomised(GomokuNet(n, 64, blocks)).eval().cuda()
     ev = FusedTowerEvaluator(net, "f32w")
@@ -89,6 +91,6 @@ def test_winograd_tower_refuses_what_it_does_not_cover():
     from alphazero_amd.fused import FusedTowerEvaluator
     from alphazero_amd.nets import GomokuNet, QuickNet
 
-    for net in (GomokuNet(9, 64, 1), GomokuNet(15, 128, 1), QuickNet(15, 15, 64, 1, 2)):
+    for net in (GomokuNet(9, 128, 1), GomokuNet(15, 128, 1), QuickNet(15, 15, 64, 1, 2)):
         with pytest.raises(EngineError):
             FusedTowerEvaluator(net.eval().cuda(), "f32w")
