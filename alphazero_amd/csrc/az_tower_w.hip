@@ -38,6 +38,8 @@
 
 #include <mutex>
 #include <string>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/az_engine.h"
 
@@ -54,7 +56,7 @@ constexpr int C = 64;
 constexpr int CSB = 264;                      // bytes per cell (64 f32 + 8)
 constexpr int STAGE_BYTES = 32768;            // U of 8 input channels (two k-steps): [j 2][kq 4][ct 4][pg 4][co 16][4 points] f32
 constexpr int KSTEP_BYTES = STAGE_BYTES / 2;  // one k-step (j): 4 input channels, one per 16-lane group kq
-constexpr int MAX_LAYERS = 40;                // bias rows kept in LDS
+constexpr int MAX_LAYERS = 36;                // bias rows kept in LDS (what the CU's 160 KiB leave beside the framed 15x15 board)
 constexpr int NTH = 512;
 constexpr int OFF_ACT = 2 * STAGE_BYTES;
 
@@ -64,19 +66,27 @@ template <int N>
 struct Geo {
   static constexpr int NV = N * N, TR = (N + 1) / 2, NT = TR * TR, GPB = (NT + 15) / 16, BPW = 4 / GPB;
   static_assert(GPB * BPW == 4, "the four tile groups of a workgroup");
-  // bytes per board row: 15 cells + 72 / 9 cells + 96 -- with CSB = 33 and RSB = 504 / 309 units of 8 B, tile (ty, tx) sits at
-  // 2 (ty RSB + tx CSB): 8 ty + tx / 5 ty + tx modulo 16 is different for the 16 tiles of a group (bank pairs of a ds_read_b64)
-  static constexpr int RSB = N == 15 ? 4032 : 2472;
-  static constexpr int BOARD_BYTES = N * RSB;
-  static constexpr int ZERO_OFF = BPW * BOARD_BYTES;         // a cell of zeros: every patch element off the board
-  static constexpr int DUMP_OFF = ZERO_OFF + CSB;            // where the outputs of cells that do not exist go
+  // The board sits in a frame of zeros: rows / columns -1 .. N + 1 (the tiles cover N + 1, their 4x4 patches reach one further on
+  // each side).  No activation is ever written there, so every patch element is a plain read at the lane's tile base + an
+  // instruction immediate: no per-element address registers, no tests.  Bytes per row: 18 cells + 48 / 12 cells + 72 -- with
+  // CSB = 33 and RSB = 600 / 405 units of 8 B, tile (ty, tx) sits at 2 (ty RSB + tx CSB): 8 ty + tx / 5 ty + tx modulo 16 is
+  // different for the 16 tiles of a group (the bank pairs of a half-wave's ds_read_b64).
+  static constexpr int HR = N + 3;
+  static constexpr int RSB = N == 15 ? 4800 : 3240;
+  static_assert(RSB >= HR * CSB, "a row holds its frame");
+  static constexpr int BOARD_BYTES = HR * RSB;
+  static constexpr int DUMP_OFF = BPW * BOARD_BYTES;         // where the outputs of cells that do not exist go
   static constexpr int ACT_BYTES = (DUMP_OFF + CSB + 15) / 16 * 16;
+  static __host__ __device__ constexpr int cell_off(int r, int c) { return (r + 1) * RSB + (c + 1) * CSB; }
   static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = 8 * SWB;  // packed input: 8 states x 2 colours x WC words
   static constexpr int RGS = RGW + 4;                        // words per board in the input buffer (ring words, the player word, pad)
   static constexpr int OFF_BL = OFF_ACT + ACT_BYTES;
   static constexpr int OFF_HW = OFF_BL + (1 + MAX_LAYERS) * C * 4;
-  static constexpr int OFF_HP = OFF_HW + 208 * 4;            // 3 x 64 head filters + 3 biases (+ pad)
-  static constexpr int OFF_RG = OFF_HP + ((BPW * 2 * 3 * NV + 3) / 4 * 4) * 4;  // [board][2 channel halves][3 heads][NV] partial head sums
+  // [board][2 channel halves][3 heads][NV] partial head sums: in the fourth weight buffer, which is idle between a board's last
+  // k-step and the next board's first (the stream's next three k-steps go to buffers 0 .. 2)
+  static constexpr int OFF_HP = 3 * KSTEP_BYTES;
+  static_assert(BPW * 2 * 3 * NV * 4 <= KSTEP_BYTES, "the head sums fit a weight buffer");
+  static constexpr int OFF_RG = OFF_HW + 208 * 4;            // (3 x 64 head filters + 3 biases (+ pad) sit at OFF_HW)
   static constexpr int OFF_SL = OFF_RG + BPW * RGS * 4;
   static constexpr int LDS_BYTES = OFF_SL + 8 * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -122,15 +132,35 @@ __device__ __forceinline__ void kstep_dma(const char *src, uint32_t dst, int wav
   for (int p = 0; p < 2; ++p) glds16(src + (p * 8 + wave) * 1024, (uint32_t)lane * 16u, dst + (p * 8 + wave) * 1024);
 }
 
-// the lane's 4x4 patch of its two input channels of stage `so / 32` (16 ds_read_b64; `so` is a compile-time constant at every
-// call: the offset travels in the instruction)
-__device__ __forceinline__ void patch_read(const uint32_t (&pa)[16], uint32_t so, f32x2 (&d)[16]) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    if (AZ_W_ABLATE & 1) d[i] = (f32x2){__uint_as_float(pa[i] + so), 1.0f};
-    else d[i] = lds_r2(pa[i] + so);
-  }
+// the lane's 4x4 patch of its two input channels of stage `so / 32` (16 ds_read_b64 at the tile's base `pb`; element and stage
+// offsets are compile-time constants: they travel in the instruction)
+// Issued from inline assembly so that the offsets DO travel in the instructions: left to itself the compiler keeps the sixteen
+// base + element sums in registers (common subexpressions of all stages), which the kernel does not have.  The compiler does not
+// count these reads in lgkmcnt: patch_wait() drains them before the transform (requests return in order, so a read the compiler
+// does not know of can only make its own counted waits stricter).
+template <int OFF>
+__device__ __forceinline__ f32x2 lds_r2_imm(uint32_t base) {
+  f32x2 r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(base), "n"(OFF));
+  return r;
 }
+template <int RSB, int SO, int... I>
+__device__ __forceinline__ void patch_read_seq(uint32_t pb, f32x2 (&d)[16], std::integer_sequence<int, I...>) {
+  ((d[I] = (AZ_W_ABLATE & 1) ? (f32x2){__uint_as_float(pb + I), 1.0f} : lds_r2_imm<(I >> 2) * RSB + (I & 3) * CSB + SO>(pb)), ...);
+}
+template <int RSB, int SO>
+__device__ __forceinline__ void patch_read(uint32_t pb, f32x2 (&d)[16]) {
+  patch_read_seq<RSB, SO>(pb, d, std::make_integer_sequence<int, 16>{});
+}
+__device__ __forceinline__ void patch_wait(f32x2 (&d)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
+  asm volatile("" : "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
+}
+// a loop whose index is a compile-time constant in the body
+template <int CNT, class F, int... I>
+__device__ __forceinline__ void static_for_seq(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int CNT, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_seq<CNT>(f, std::make_integer_sequence<int, CNT>{}); }
 // V = B^T d B (32 two-channel adds), point 4 i + q
 __device__ __forceinline__ void patch_transform(const f32x2 (&d)[16], f32x2 (&v)[16]) {
   f32x2 t[16];
@@ -189,35 +219,36 @@ __device__ __forceinline__ void kstep_mfma(uint32_t ab, uint32_t abn, f32x4 &a, 
 // the V formed one stage (two k-steps) ago; the next stage's patch is requested between the stage's two k-steps and
 // transformed after the second.  f32 MFMAs and ordinary VALU instructions share the SIMD's multipliers (nothing co-executes:
 // az_tower_f32.hip), so every VALU instruction in this loop is MFMA time: immediates, no address arithmetic.
-template <int NS>
-__device__ __forceinline__ void conv_w(uint32_t lds0, const uint32_t (&pa)[16], uint32_t abase, const char *wg, const char *wnext,
+template <int NS, int RSB>
+__device__ __forceinline__ void conv_w(uint32_t lds0, uint32_t pb, uint32_t abase, const char *wg, const char *wnext,
                                        int wave, int lane, f32x4 (&acc)[16][2]) {
   constexpr int T = 2 * NS;
   static_assert(T % 4 == 0, "a layer ends in the buffer it started in");
   f32x2 d[16], v[16];
   f32x4 a;
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
+  static_for<T>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if (t == 0 || !(AZ_W_ABLATE & 2)) lds_barrier();
     if (!(AZ_W_ABLATE & 16)) kstep_dma(t + 3 < T ? wg + (size_t)(t + 3) * KSTEP_BYTES : wnext + (size_t)(t + 3 - T) * KSTEP_BYTES,
                                        lds0 + (uint32_t)(((t + 3) & 3) * KSTEP_BYTES), wave, lane);
     const uint32_t ab = abase + (uint32_t)((t & 3) * KSTEP_BYTES), abn = abase + (uint32_t)(((t + 1) & 3) * KSTEP_BYTES);
-    if (t == 0) {
+    if constexpr (t == 0) {
       a = lds_r4(ab);
-      patch_read(pa, 0u, d);
+      patch_read<RSB, 0>(pb, d);
+      patch_wait(d);
       patch_transform(d, v);
     }
-    if ((t & 1) && t + 1 < T) {  // in flight under this k-step's MFMAs (left alone the scheduler sinks them to the barrier to save registers)
-      patch_read(pa, (uint32_t)(t / 2 + 1) * 32u, d);
+    if constexpr ((t & 1) && t + 1 < T) {  // in flight under this k-step's MFMAs (left alone the scheduler sinks them to the barrier to save registers)
+      patch_read<RSB, (t / 2 + 1) * 32>(pb, d);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (t == 0) kstep_mfma<true, false, 0>(ab, abn, a, v, acc);
-    else if (t + 1 == T) kstep_mfma<false, true, 1>(ab, abn, a, v, acc);
-    else if (t & 1) kstep_mfma<false, false, 1>(ab, abn, a, v, acc);
-    else kstep_mfma<false, false, 0>(ab, abn, a, v, acc);
-    if ((t & 1) && t + 1 < T) patch_transform(d, v);
-  }
+    kstep_mfma<t == 0, t + 1 == T, (t & 1)>(ab, abn, a, v, acc);
+    if constexpr ((t & 1) && t + 1 < T) {
+      patch_wait(d);
+      patch_transform(d, v);
+    }
+  });
 }
 
 template <int N>
@@ -229,7 +260,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
                                                         unsigned int *tickets) {
   using Q = Geo<N>;
   constexpr int NV = Q::NV, TR = Q::TR, NT = Q::NT, GPB = Q::GPB, BPW = Q::BPW, RSB = Q::RSB, BOARD_BYTES = Q::BOARD_BYTES;
-  constexpr int ZERO_OFF = Q::ZERO_OFF, DUMP_OFF = Q::DUMP_OFF, ACT_BYTES = Q::ACT_BYTES, WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RGS = Q::RGS;
+  constexpr int DUMP_OFF = Q::DUMP_OFF, ACT_BYTES = Q::ACT_BYTES, WC = Q::WC, SWB = Q::SWB, RGW = Q::RGW, RGS = Q::RGS;
   extern __shared__ __attribute__((aligned(1024))) char smem_w[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem_w;
   const uint32_t act0 = lds0 + OFF_ACT;
@@ -244,16 +275,13 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
   const int wb = (wave & 3) / GPB, tg = (wave & 3) % GPB;  // the wave's board of the workgroup and tile group of that board
   const int tile = 16 * tg + n, ty = tile / TR, tx = tile - ty * TR;  // (tile >= NT: an idle lane -- reads zeros, writes to the dump cell)
 
-  for (int i = tid; i < ACT_BYTES / 16; i += NTH) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // incl. the zero and dump cells
+  for (int i = tid; i < ACT_BYTES / 16; i += NTH) ((uint4 *)act)[i] = make_uint4(0, 0, 0, 0);  // the frames stay zero for good
   for (int i = tid; i < (1 + L) * C; i += NTH) bl[i] = bias[i];
   for (int i = tid; i < 3 * C + 3; i += NTH) hw[i] = i < 3 * C ? headw[i] : headb[i - 3 * C];
 
-  uint32_t pa[16];  // the lane's 4x4 input patch: rows 2 ty - 1 .. + 3, columns 2 tx - 1 .. + 3, its channel pair 2 kq (+ 8 s)
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int r = 2 * ty - 1 + (i >> 2), c = 2 * tx - 1 + (i & 3);
-    pa[i] = act0 + (uint32_t)((tile < NT && r >= 0 && r < N && c >= 0 && c < N ? wb * BOARD_BYTES + r * RSB + c * CSB : ZERO_OFF) + kq * 8);
-  }
+  // the lane's 4x4 input patch starts at cell (2 ty - 1, 2 tx - 1) = frame cell (2 ty, 2 tx); its channel pair 2 kq (+ 8 per stage).
+  // (An idle lane of a 9x9 group reads tile 0's patch: finite values whose results go to the dump cell.)
+  const uint32_t pb = act0 + (uint32_t)(wb * BOARD_BYTES + (tile < NT ? 2 * ty * RSB + 2 * tx * CSB : 0) + kq * 8);
   // Everything the epilogues need per lane (its output cells, its channels) is re-derived from a laundered copy of the lane index
   // inside each epilogue: hoisted out of the board loop these values would sit in registers through the conv loops, which run
   // at the register budget (a spill there is a scratch load, and a scratch load is a vmcnt(0) in the weight stream)
@@ -285,7 +313,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 2 * ty_ + (i >> 1), c = 2 * tx_ + (i & 1);
-      oc[i] = act0 + (uint32_t)((tile_ < NT && r < N && c < N ? wb * BOARD_BYTES + r * RSB + c * CSB : DUMP_OFF) + bo * 4);
+      oc[i] = act0 + (uint32_t)((tile_ < NT && r < N && c < N ? wb * BOARD_BYTES + Q::cell_off(r, c) : DUMP_OFF) + bo * 4);
     }
     f32x4 y[4][2];  // [output 2 a + b][ct] (4 channels r)
 #pragma unroll
@@ -381,7 +409,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
             c[k] = (float)(int)((rg[k * SWB + wi] >> sh) & 1u) - (float)(int)((rg[k * SWB + WC + wi] >> sh) & 1u);
           c[8] = (int)rg[RGW] > 0 ? 1.0f : -1.0f;
         }
-        const uint32_t a = act0 + (uint32_t)(b * BOARD_BYTES + row * RSB + col * CSB);
+        const uint32_t a = act0 + (uint32_t)(b * BOARD_BYTES + Q::cell_off(row, col));
 #pragma unroll
         for (int k = 0; k < 8; ++k) lds_w2(a + 8 * k, (f32x2){c[2 * k], c[2 * k + 1]});
       }
@@ -402,7 +430,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     }
     // (the first stage's barrier orders the input planes before the patch reads)
     WSTAMP(3);
-    conv_w<2>(lds0, pa, abase, u0, L > 0 ? ul : u0, wave, lane, acc);
+    conv_w<2, RSB>(lds0, pb, abase, u0, L > 0 ? ul : u0, wave, lane, acc);
     WSTAMP(4);
     __syncthreads();  // every wave has read the layer's input: the outputs may overwrite it
     WSTAMP(5);
@@ -410,13 +438,13 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     WSTAMP(6);
     for (int l = 0; l < L; l += 2) {
       const char *w1 = ul + (size_t)l * 8 * STAGE_BYTES, *w2 = w1 + (size_t)8 * STAGE_BYTES;
-      conv_w<8>(lds0, pa, abase, w1, w2, wave, lane, acc);
+      conv_w<8, RSB>(lds0, pb, abase, w1, w2, wave, lane, acc);
       WSTAMP(7 + 3 * l);
       __syncthreads();
       WSTAMP(8 + 3 * l);
       epilogue(true, bl + (2 + l) * C);
       WSTAMP(9 + 3 * l);
-      conv_w<8>(lds0, pa, abase, w2, l + 2 < L ? w2 + (size_t)8 * STAGE_BYTES : u0, wave, lane, acc);
+      conv_w<8, RSB>(lds0, pb, abase, w2, l + 2 < L ? w2 + (size_t)8 * STAGE_BYTES : u0, wave, lane, acc);
       WSTAMP(10 + 3 * l);
       __syncthreads();
       WSTAMP(11 + 3 * l);
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     if (tid < BPW * 2 * NV) {
       const int b = BPW == 1 ? 0 : tid / (2 * NV), e = tid - b * 2 * NV;
       const int half = e >= NV ? 1 : 0, cell = e - half * NV, row = cell / N, col = cell - row * N;
-      const uint32_t a = act0 + (uint32_t)(b * BOARD_BYTES + row * RSB + col * CSB + half * 128);
+      const uint32_t a = act0 + (uint32_t)(b * BOARD_BYTES + Q::cell_off(row, col) + half * 128);
       const float *w = hw + half * 32;
       float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -490,7 +518,7 @@ extern "C" int az_tower_forward_f32w(int32_t board_size, int32_t channels, int32
   if ((!x_f32_dev && (!packed_ring_dev || !packed_leaf_dev)) || !u0_dev || !bias_dev || !headw_dev || !headb_dev || !feat_f32_dev ||
       (n_conv_layers > 0 && !ul_dev)) { tower_set_error("null argument"); return AZ_EINVAL; }
   if (n_boards < 1 || n_conv_layers < 0 || (n_conv_layers & 1) || n_conv_layers > MAX_LAYERS) {
-    tower_set_error("Winograd f32 tower: n_boards >= 1, an even number of conv layers, at most 40");
+    tower_set_error("Winograd f32 tower: n_boards >= 1, an even number of conv layers, at most 36");
     return AZ_EINVAL;
   }
   if ((board_size != 15 && board_size != 9) || channels != 64) { tower_set_error("Winograd f32 tower: 9x9 or 15x15 boards, 64 channels"); return AZ_EINVAL; }

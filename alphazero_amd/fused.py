@@ -236,9 +236,9 @@ class FusedTowerEvaluator:
 
     @classmethod
     def winograd_supports(cls, model: nn.Module) -> bool:
-        """the Winograd f32 tower (csrc/az_tower_w.hip; precision "f32w"): 64-channel GomokuModel family on 9x9 or 15x15, <= 40 conv layers"""
+        """the Winograd f32 tower (csrc/az_tower_w.hip; precision "f32w"): 64-channel GomokuModel family on 9x9 or 15x15, <= 36 conv layers"""
         return (cls.supports(model) and cls.quick_shape(model) is None and model._shared_layers[0].out_channels == 64
-                and 2 * (len(model._shared_layers) - 3) <= 40)
+                and 2 * (len(model._shared_layers) - 3) <= 36)
 
     def __init__(self, model: nn.Module, precision: str = "bf16"):
         """precision: "bf16" (az_tower.hip: bf16 operands, f32 accumulation -- the throughput mode), "f32"
@@ -262,7 +262,7 @@ class FusedTowerEvaluator:
             raise EngineError("FusedTowerEvaluator: the row-tile tower (f16 / bf16r) covers 64-channel GomokuModel-family networks on 15x15")
         if precision == "f32w" and not self.winograd_supports(model):
             raise EngineError("FusedTowerEvaluator: the Winograd f32 tower (f32w) covers 64-channel GomokuModel-family networks "
-                              "(9x9 or 15x15), at most 20 residual blocks")
+                              "(9x9 or 15x15), at most 18 residual blocks")
         if self.quick is not None:
             self.board, self.ch, self.q_blocks, self.q_layers = self.quick
             self.n2 = self.board * self.board

@@ -437,8 +437,8 @@ def test_winograd_weight_packing_reproduces_the_convolution():
                 y[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = at @ m @ at.t()
         ref = Fn.conv2d(x, w.double(), padding=1)
         assert float((y[:, :, :15, :15] - ref).abs().max()) < 1e-6
-    assert F.winograd_supports(nets.GomokuNet(15, 64, 2)) and F.winograd_supports(nets.GomokuNet(15, 64, 20))
-    assert not F.winograd_supports(nets.GomokuNet(15, 64, 21)) and F.winograd_supports(nets.GomokuNet(9, 64, 2))
+    assert F.winograd_supports(nets.GomokuNet(15, 64, 2)) and F.winograd_supports(nets.GomokuNet(15, 64, 18))
+    assert not F.winograd_supports(nets.GomokuNet(15, 64, 19)) and F.winograd_supports(nets.GomokuNet(9, 64, 2))
     assert not F.winograd_supports(nets.GomokuNet(15, 128, 2)) and not F.winograd_supports(nets.QuickNet(15, 9, 64, 1, 2))
 
 
