@@ -152,6 +152,14 @@ template <int RSB, int SO>
 __device__ __forceinline__ void patch_read(uint32_t pb, f32x2 (&d)[16]) {
   patch_read_seq<RSB, SO>(pb, d, std::make_integer_sequence<int, 16>{});
 }
+// ... two elements at a time (2 g, 2 g + 1): spread over the eight MFMA groups of a k-step, so that no U read queues behind
+// sixteen patch reads (LDS requests return in order)
+template <int RSB, int SO, int G2>
+__device__ __forceinline__ void patch_read_pair(uint32_t pb, f32x2 (&d)[16]) {
+  if (AZ_W_ABLATE & 1) { d[2 * G2] = (f32x2){__uint_as_float(pb), 1.0f}; d[2 * G2 + 1] = d[2 * G2]; return; }
+  d[2 * G2] = lds_r2_imm<((2 * G2) >> 2) * RSB + ((2 * G2) & 3) * CSB + SO>(pb);
+  d[2 * G2 + 1] = lds_r2_imm<((2 * G2 + 1) >> 2) * RSB + ((2 * G2 + 1) & 3) * CSB + SO>(pb);
+}
 __device__ __forceinline__ void patch_wait(f32x2 (&d)[16]) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
   asm volatile("" : "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
@@ -184,20 +192,42 @@ __device__ __forceinline__ void patch_transform(const f32x2 (&d)[16], f32x2 (&v)
 // before), and the last group's slot requests group 0 of the NEXT k-step from `abn` (its buffer has landed and is visible:
 // conv_w) -- no U read is waited for right after a barrier.  FIRST: the layer's first k-step -- only the four points that
 // carry bias / residual (0, 3, 12, 15) have live accumulators, the others start from the instruction's zero operand.
-template <bool FIRST, bool LAST, int J>
-__device__ __forceinline__ void kstep_mfma(uint32_t ab, uint32_t abn, f32x4 &a, const f32x2 (&v)[16], f32x4 (&acc)[16][2]) {
-  auto uread = [&](uint32_t base, int g) -> f32x4 {
-    if (AZ_W_ABLATE & 4) return (f32x4){__uint_as_float(base), 1.0f, 2.0f, 3.0f};
-    return lds_r4(base + (uint32_t)((g & 1) * 1024 + (g >> 1) * 256));
-  };
-  f32x4 a0n = a;  // group 0 of the next k-step: requested half a k-step before the barrier that follows this one
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {  // group g: point row i = g >> 1, channel tile ct = g & 1
-    const int i = g >> 1, ct = g & 1;
+// U reads as inline assembly too (offset in the instruction), so that EVERY LDS read of the conv loop is outside the compiler's
+// lgkmcnt bookkeeping and the waits can be counted by hand: requests return in order, and mixing counted with uncounted reads makes
+// the compiler's own waits drain the queue.
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_r4_imm(uint32_t base) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(base), "n"(OFF));
+  return r;
+}
+template <int CNT>
+__device__ __forceinline__ void lgkm_wait(f32x4 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+// LDS requests group g of a k-step issues, in this order: U of group g + 2, U of the next k-step's group 0 / 1 (g = 2 / 3), two
+// patch elements (PATCH: a k-step under which the next stage's patch is fetched)
+template <bool LAST, bool PATCH>
+__host__ __device__ constexpr int kstep_issued(int g) { return g < 0 ? 0 : (g + 2 < 8 ? 1 : 0) + (!LAST && (g == 2 || g == 3) ? 1 : 0) + (PATCH ? 2 : 0); }
+
+// the 32 MFMAs of a k-step (channel J of the lane's pair): 16 points x 2 channel tiles.  U comes from the k-step's buffer at `ab`
+// in 8 ds_read_b128, each requested TWO groups of four MFMAs ahead: groups 0 and 1 arrive in `a`, `a1` (requested during the k-step
+// before: the next k-step's buffer has landed and is visible, conv_w); PATCH: the 16 patch reads of the next stage ride along, two
+// per group.  Before group g's MFMAs: lgkmcnt(everything issued after U(g)).  FIRST: the layer's first k-step -- only the four
+// points that carry bias / residual (0, 3, 12, 15) have live accumulators, the others start from the instruction's zero operand.
+template <bool FIRST, bool LAST, bool PATCH, int J, int RSB, int SO>
+__device__ __forceinline__ void kstep_mfma(uint32_t ab, uint32_t abn, uint32_t pb, f32x4 &a, f32x4 &a1, const f32x2 (&v)[16], f32x2 (&d)[16],
+                                           f32x4 (&acc)[16][2]) {
+  f32x4 a0n = a, a1n = a1;
+  static_for<8>([&](auto gc) {  // group g: point row i = g >> 1, channel tile ct = g & 1
+    constexpr int g = decltype(gc)::value, i = g >> 1, ct = g & 1;
     f32x4 an = a;
-    if (g + 1 < 8) an = uread(ab, g + 1);
-    else an = a0n;
-    if (g == 3 && !LAST) a0n = uread(abn, 0);
+    if constexpr (g + 2 < 8) an = lds_r4_imm<((g + 2) & 1) * 1024 + ((g + 2) >> 1) * 256>(ab);
+    if constexpr (g == 2 && !LAST) a0n = lds_r4_imm<0>(abn);
+    if constexpr (g == 3 && !LAST) a1n = lds_r4_imm<1024>(abn);
+    if constexpr (PATCH) patch_read_pair<RSB, SO, g>(pb, d);
+    // (groups 0, 1: their U was requested a k-step ago and drained by the barrier's lgkmcnt(0); the wait -- everything this k-step
+    // has issued so far may stay in flight -- only ties the MFMAs behind that barrier for the compiler)
+    if constexpr (g >= 2) lgkm_wait<kstep_issued<LAST, PATCH>(g - 2) - 1 + kstep_issued<LAST, PATCH>(g - 1) + kstep_issued<LAST, PATCH>(g)>(a);
+    else lgkm_wait<kstep_issued<LAST, PATCH>(g - 1) + kstep_issued<LAST, PATCH>(g)>(a);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int p = 4 * i + q;
@@ -205,8 +235,10 @@ __device__ __forceinline__ void kstep_mfma(uint32_t ab, uint32_t abn, f32x4 &a, 
       if (AZ_W_ABLATE & 8) acc[p][ct][q] = (fresh ? 0.0f : acc[p][ct][q]) + a[q] * v[p][J];
       else acc[p][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], v[p][J], fresh ? (f32x4){0.0f, 0.0f, 0.0f, 0.0f} : acc[p][ct], 0, 0, 0);
     }
-    a = an;
-  }
+    a = a1;
+    if constexpr (g + 2 < 8) a1 = an;
+    else a1 = g == 6 ? a0n : a1n;
+  });
 }
 
 // One conv layer in the transform domain: acc[point][ct] = (preloaded bias / residual) + U V over T = 2 NS k-steps of 4 input
@@ -225,7 +257,7 @@ __device__ __forceinline__ void conv_w(uint32_t lds0, uint32_t pb, uint32_t abas
   constexpr int T = 2 * NS;
   static_assert(T % 4 == 0, "a layer ends in the buffer it started in");
   f32x2 d[16], v[16];
-  f32x4 a;
+  f32x4 a, a1;
   static_for<T>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -234,16 +266,16 @@ __device__ __forceinline__ void conv_w(uint32_t lds0, uint32_t pb, uint32_t abas
                                        lds0 + (uint32_t)(((t + 3) & 3) * KSTEP_BYTES), wave, lane);
     const uint32_t ab = abase + (uint32_t)((t & 3) * KSTEP_BYTES), abn = abase + (uint32_t)(((t + 1) & 3) * KSTEP_BYTES);
     if constexpr (t == 0) {
-      a = lds_r4(ab);
+      a = lds_r4_imm<0>(ab);
+      a1 = lds_r4_imm<1024>(ab);
       patch_read<RSB, 0>(pb, d);
-      patch_wait(d);
+      patch_wait(d);  // (lgkmcnt(0): the two U reads as well)
+      lgkm_wait<0>(a);
+      lgkm_wait<0>(a1);
       patch_transform(d, v);
     }
-    if constexpr ((t & 1) && t + 1 < T) {  // in flight under this k-step's MFMAs (left alone the scheduler sinks them to the barrier to save registers)
-      patch_read<RSB, (t / 2 + 1) * 32>(pb, d);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    kstep_mfma<t == 0, t + 1 == T, (t & 1)>(ab, abn, a, v, acc);
+    // (odd k-steps: the next stage's patch in flight under the MFMAs, two elements per MFMA group)
+    kstep_mfma<t == 0, t + 1 == T, ((t & 1) && t + 1 < T), (t & 1), RSB, (t / 2 + 1) * 32>(ab, abn, pb, a, a1, v, d, acc);
     if constexpr ((t & 1) && t + 1 < T) {
       patch_wait(d);
       patch_transform(d, v);
