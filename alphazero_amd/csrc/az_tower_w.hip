@@ -79,7 +79,7 @@ struct Geo {
   static constexpr int ACT_BYTES = (DUMP_OFF + CSB + 15) / 16 * 16;
   static __host__ __device__ constexpr int cell_off(int r, int c) { return (r + 1) * RSB + (c + 1) * CSB; }
   static constexpr int WC = (NV + 31) / 32, SWB = 2 * WC, RGW = 8 * SWB;  // packed input: 8 states x 2 colours x WC words
-  static constexpr int RGS = RGW + 4;                        // words per board in the input buffer (ring words, the player word, pad)
+  static constexpr int RGS = RGW + 1;                        // words per board in an input buffer: the ring words, the player word
   static constexpr int OFF_BL = OFF_ACT + ACT_BYTES;
   static constexpr int OFF_HW = OFF_BL + (1 + MAX_LAYERS) * C * 4;
   // [board][2 channel halves][3 heads][NV] partial head sums: in the fourth weight buffer, which is idle between a board's last
@@ -87,8 +87,8 @@ struct Geo {
   static constexpr int OFF_HP = 3 * KSTEP_BYTES;
   static_assert(BPW * 2 * 3 * NV * 4 <= KSTEP_BYTES, "the head sums fit a weight buffer");
   static constexpr int OFF_RG = OFF_HW + 208 * 4;            // (3 x 64 head filters + 3 biases (+ pad) sit at OFF_HW)
-  static constexpr int OFF_SL = OFF_RG + BPW * RGS * 4;
-  static constexpr int LDS_BYTES = OFF_SL + 8 * 4;
+  static constexpr int OFF_SL = OFF_RG + (2 * BPW * RGS * 4 + 15) / 16 * 16;  // two input buffers: the running ticket's, the one fetched ahead
+  static constexpr int LDS_BYTES = OFF_SL + 16 * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
   static_assert(OFF_BL % 16 == 0 && OFF_HW % 16 == 0 && OFF_HP % 16 == 0 && OFF_RG % 16 == 0, "alignment");
   static_assert(BPW * 2 * NV <= NTH && BPW * NV <= NTH && BPW * (RGW + 1) <= NTH, "one pass of the workgroup per phase");
@@ -120,6 +120,10 @@ __device__ __forceinline__ void lds_w2(uint32_t a, f32x2 v) { *LDS_PTR(f32x2, a)
 // (address = wave-uniform 64-bit base in SGPRs + the lane's 32-bit byte offset: no VALU, no 64-bit VGPR pointers.)
 __device__ __forceinline__ void glds16(const char *g_base, uint32_t lane_off, uint32_t lds_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_base), "v"(lane_off), "s"(g_base) : "memory");
+}
+// ... of 4 B per lane (the packed input words and the flag bytes fetched a ticket ahead)
+__device__ __forceinline__ void glds4(const void *g_base, uint32_t lane_off, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(lds_base), "v"(lane_off), "s"(g_base) : "memory");
 }
 // workgroup barrier that orders LDS accesses only: __syncthreads() also drains every outstanding LDS-DMA (vmcnt(0)), which
 // would serialise the weight stream that runs three k-steps ahead; what has to have landed is waited for explicitly (vmcnt(2))
@@ -301,7 +305,10 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
   float *hw = (float *)(smem_w + Q::OFF_HW);
   float *hp = (float *)(smem_w + Q::OFF_HP);
   uint32_t *rgb = (uint32_t *)(smem_w + Q::OFF_RG);
-  int *slots = (int *)(smem_w + Q::OFF_SL);  // {this ticket (group of BPW boards), the next ticket, its flag (-1: not read), -, 4 + b: board b is evaluated}
+  // {0: this ticket (a group of BPW boards), 1: the next ticket, 2: which of its boards are evaluated (bit b; -1: not known yet),
+  //  3: the ticket whose packed input sits in the input buffer the running ticket does not use (-1: none), 4 + b: board b of this
+  //  ticket is evaluated, 6: landing word of the flag bytes fetched ahead, 7: the ticket to fetch ahead (-1: none), 8: its boards}
+  int *slots = (int *)(smem_w + Q::OFF_SL);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, kq = lane >> 4, chalf = wave >> 2;
   const int wb = (wave & 3) / GPB, tg = (wave & 3) % GPB;  // the wave's board of the workgroup and tile group of that board
@@ -321,8 +328,9 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
   const uint32_t abase = lds0 + (uint32_t)(kq * 4096 + chalf * 2048 + n * 16);  // U of a k-step: [kq 4][ct 4][i 4][co 16][q 4]
 
   for (int t = 0; t < 3; ++t) kstep_dma(u0 + t * KSTEP_BYTES, lds0 + (uint32_t)(t * KSTEP_BYTES), wave, lane);  // the stem's first three k-steps
-  if (tid == 0) { slots[1] = (int)blockIdx.x; slots[2] = -1; }
+  if (tid == 0) { slots[1] = (int)blockIdx.x; slots[2] = -1; slots[3] = -1; slots[6] = 0; slots[7] = -1; slots[8] = 0; }
   __syncthreads();
+  int rsel = 0;  // (uniform) which input buffer the running ticket expands
 
   f32x4 acc[16][2];
   // A^T M A sends M[0][0], -M[0][3], -M[3][0], M[3][3] to outputs 00, 01, 10, 11: the accumulators of these four points carry
@@ -392,13 +400,12 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     WSTAMP(0);
     if (tid == 0) {  // this ticket: the one drawn ahead, or -- when none of its leaves needs the network (flags off) -- the next that does
       int tk = slots[1], fl = slots[2];
-      constexpr int NGdiv = BPW;
-      const int NG = (G + NGdiv - 1) / NGdiv;
+      const int NG = (G + BPW - 1) / BPW;
       while (tk < NG && flags != nullptr) {
         if (fl < 0) {
           fl = 0;
 #pragma unroll
-          for (int b = 0; b < BPW; ++b) fl |= tk * BPW + b < G ? (int)flags[tk * BPW + b] : 0;
+          for (int b = 0; b < BPW; ++b) fl |= tk * BPW + b < G && flags[tk * BPW + b] != 0 ? 1 << b : 0;
         }
         if (fl != 0) break;
         tk = (int)(gridDim.x + atomicAdd(&tickets[0], 1u));
@@ -406,8 +413,7 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
       }
       slots[0] = tk;
 #pragma unroll
-      for (int b = 0; b < BPW; ++b)
-        slots[4 + b] = tk < NG && tk * BPW + b < G && (flags == nullptr || flags[tk * BPW + b] != 0) ? 1 : 0;
+      for (int b = 0; b < BPW; ++b) slots[4 + b] = tk < NG && tk * BPW + b < G && (flags == nullptr || ((fl >> b) & 1) != 0) ? 1 : 0;
     }
     __syncthreads();
     const int gt = slots[0];
@@ -415,18 +421,23 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     const int g = gt * BPW;  // the ticket's first board
     WSTAMP(1);
     unsigned int drawn = 0;
-    if (tid == 0) drawn = atomicAdd(&tickets[0], 1u);  // the next ticket (lands while the input is fetched)
+    if (tid == 0) drawn = atomicAdd(&tickets[0], 1u);  // the next ticket (lands while the input is expanded)
     if (x == nullptr) {
-      if (tid < BPW * (RGW + 1)) {
-        const int b = BPW == 1 ? 0 : tid / (RGW + 1), i = tid - b * (RGW + 1);
-        if (slots[4 + b] != 0) rgb[b * RGS + i] = i < RGW ? ring[(size_t)(g + b) * RGW + i] : (uint32_t)leafrec[g + b].w;
+      if (__builtin_amdgcn_readfirstlane((int)(slots[3] == gt)) != 0) {
+        rsel ^= 1;  // fetched ahead, under the ticket before (below): it sits in the other buffer
+      } else {
+        if (tid < BPW * RGS) {
+          const int b = BPW == 1 ? 0 : tid / RGS, i = tid - b * RGS;
+          if (slots[4 + b] != 0) rgb[rsel * BPW * RGS + tid] = i < RGW ? ring[(size_t)(g + b) * RGW + i] : (uint32_t)leafrec[g + b].w;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
+    const uint32_t *rgc = rgb + rsel * BPW * RGS;
     if (tid < BPW * NV) {
       const int b = BPW == 1 ? 0 : tid / NV, cell = tid - b * NV, row = cell / N, col = cell - row * N;
       if (slots[4 + b] != 0) {  // (a board that is not evaluated keeps whatever its region holds: finite values, results discarded)
-        const uint32_t *rg = rgb + b * RGS;
+        const uint32_t *rg = rgc + b * RGS;
         float c[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) c[k] = 0.0f;
@@ -446,9 +457,18 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
         for (int k = 0; k < 8; ++k) lds_w2(a + 8 * k, (f32x2){c[2 * k], c[2 * k + 1]});
       }
     }
+    // The NEXT ticket is looked up while this one is computed, in steps that are never waited for: its number is known here; the
+    // flag bytes of its boards (one aligned word) travel into slots[6] by LDS-DMA under the stem (the conv loop's own vmcnt waits
+    // cover them: requests return in order); after the stem the ticket to fetch is published; after the first block's first conv
+    // its boards' packed input is sent into the input buffer this ticket does not use, again by LDS-DMA.  (The copies are issued
+    // from inline assembly like the weight stream's: one more in front of a k-step's two only makes that k-step's vmcnt(2) stricter.)
     if (tid == 0) {
-      slots[1] = (int)(gridDim.x + drawn);
+      const int nx = (int)(gridDim.x + drawn);
+      slots[1] = nx;
       slots[2] = -1;
+      slots[7] = -1;
+      if (nx < (G + BPW - 1) / BPW && flags != nullptr && x == nullptr && L > 0)
+        glds4(flags, (uint32_t)(nx * BPW) & ~3u, lds0 + (uint32_t)(Q::OFF_SL + 6 * 4));
     }
     {  // stem: accumulators start at its bias
       f32x4 pre[4][2];
@@ -468,10 +488,35 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     WSTAMP(5);
     epilogue(false, L > 0 ? bl + C : nullptr);
     WSTAMP(6);
+    if (tid == 0 && L > 0 && x == nullptr) {  // the ticket to fetch ahead: the next one when any of its leaves needs the network (else it is resolved at the top)
+      const int nx = slots[1];
+      int mask = 0;
+      if (nx < (G + BPW - 1) / BPW) {
+        const int w = *(volatile int *)(slots + 6), sh = 8 * ((nx * BPW) & 3);
+#pragma unroll
+        for (int b = 0; b < BPW; ++b)
+          if (nx * BPW + b < G && (flags == nullptr || ((w >> (sh + 8 * b)) & 0xFF) != 0)) mask |= 1 << b;
+        if (flags != nullptr) slots[2] = mask;
+      }
+      slots[8] = mask;
+      slots[7] = mask != 0 ? nx : -1;
+    }
     for (int l = 0; l < L; l += 2) {
       const char *w1 = ul + (size_t)l * 8 * STAGE_BYTES, *w2 = w1 + (size_t)8 * STAGE_BYTES;
       conv_w<8, RSB>(lds0, pb, abase, w1, w2, wave, lane, acc);
       WSTAMP(7 + 3 * l);
+      if (l == 0 && x == nullptr) {  // (slots[7], slots[8] were written before this conv's barriers)
+        const int pf = __builtin_amdgcn_readfirstlane(slots[7]);
+        if (pf >= 0 && tid < BPW * RGS) {  // word `tid` of the other input buffer: board b's ring word i / its player word
+          const int b = BPW == 1 ? 0 : tid / RGS, i = tid - b * RGS;
+          const uint32_t dst = lds0 + (uint32_t)(Q::OFF_RG + ((rsel ^ 1) * BPW * RGS + wave * 64) * 4);
+          if (((slots[8] >> b) & 1) != 0) {
+            if (i < RGW) glds4(ring, (uint32_t)((pf * BPW + b) * RGW + i) * 4u, dst);
+            else glds4(leafrec, (uint32_t)(pf * BPW + b) * 16u + 12u, dst);
+          }
+          if (tid == 0) slots[3] = pf;
+        }
+      }
       __syncthreads();
       WSTAMP(8 + 3 * l);
       epilogue(true, bl + (2 + l) * C);
