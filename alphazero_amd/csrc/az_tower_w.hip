@@ -12,14 +12,14 @@
 // 64->64 layer and board against the direct convolution's 8,640 (az_tower_f32.hip).  The MFMA pipe still bounds the kernel
 // (157.3 TFLOP/s dense f32); the transforms are a few dozen VALU instructions per 64 MFMAs.
 //
-// One workgroup of 8 waves owns one board at a time for the whole tower; activations live in LDS (act[row][col][64 ch] f32,
-// 264 B per cell, 4,032 B per row: with these two pitches the 16 tiles x 2 channel pairs of a half-wave's ds_read_b64 fall on
-// 32 different bank pairs), layers run in place.  Wave w = (tile group tg = w & 3: tile rows 2 tg, 2 tg + 1 x 8 tile columns
-// = the N = 16 of the MFMA; channel half ch = w >> 2: 2 tiles of 16 output channels) and holds ALL 16 transform points of its
-// 16 tiles x 32 channels in 128 accumulator registers, so that
-//   * a lane builds its B operands itself: it reads the 4x4 patch of its tile for 2 input channels (16 ds_read_b64, addresses
-//     fixed per lane: cells off the board point at a zero cell), forms V = B^T d B in registers (32 packed adds) and feeds 64
-//     MFMAs (16 points x 2 channel tiles x 2 k-steps) with it -- the transformed input never exists in memory;
+// One workgroup of 8 waves owns one board at a time for the whole tower (9x9: two boards); activations live in LDS, the board
+// inside a frame of zeros (act[row -1 .. 16][col -1 .. 16][64 ch] f32, 264 B per cell, 4,800 B per row: with these two pitches the
+// 16 tiles x 2 channel pairs of a half-wave's ds_read_b64 fall on 32 different bank pairs), layers run in place.  Wave w = (tile
+// group tg = w & 3: tile rows 2 tg, 2 tg + 1 x 8 tile columns = the N = 16 of the MFMA; channel half ch = w >> 2: 2 tiles of 16
+// output channels) and holds ALL 16 transform points of its 16 tiles x 32 channels in 128 accumulator registers, so that
+//   * a lane builds its B operands itself: it reads the 4x4 patch of its tile for 2 input channels (16 ds_read_b64 at the tile's
+//     base + instruction immediates: the frame makes every element a plain read), forms V = B^T d B in registers (32 two-channel
+//     adds) and feeds 64 MFMAs (16 points x 2 channel tiles x 2 k-steps) with it -- the transformed input never exists in memory;
 //   * the inverse transform A^T M A is in-lane too: the 16 M_p of an (output channel, tile) pair are 16 registers of one lane.
 // Transformed weights U (host: G g G^T in f64, rounded to f32; 256 KiB per layer) stream L2 -> LDS by LDS-DMA in k-steps of 4
 // input channels (16 KiB) through four buffers, three k-steps ahead of their use and straight across layer and board boundaries
@@ -28,7 +28,8 @@
 // to the four outputs of the tile one to one, so the lane that overwrites a block's input in the first conv's epilogue reads it
 // there and starts the second conv's accumulators at bias + x (as az_tower_f32.hip); the other twelve accumulators of a tile start
 // from the first MFMA's zero operand.  What bounds the kernel (measured): f32 MFMAs and VALU instructions do not
-// co-execute, so the transforms' adds are MFMA time -- MFMA pipe busy 0.71, VALU 0.22.
+// co-execute, so the transforms' adds are MFMA time -- MFMA pipe busy 0.76, other VALU 0.13.  Every LDS-DMA and every LDS read of
+// the conv loop is issued from inline assembly with hand-counted vmcnt / lgkmcnt waits (see glds16, lds_r2_imm, kstep_mfma).
 // Boards are handed out by the library's ticket counter (az_tower.hip); the input is the engine's packed leaf batch (8
 // bitboards + player) with its needs-the-network flags, or dense f32 planes.  Output: the f32 feature rows k_heads_f32 reads.
 // C ABI at the bottom; declared in include/az_engine.h.
