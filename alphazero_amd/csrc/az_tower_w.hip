@@ -345,49 +345,55 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
       acc[15][ct] = pre[3][ct];
     }
   };
-  // inverse transform, ReLU, store in place; the next layer's accumulators start at its bias (+ the activations this lane
-  // overwrites, when they are the residual of the block's second conv)
-  auto epilogue = [&](bool with_res, const float *bnext) {
+  // The epilogue of a layer.  Part 1, BEFORE the barrier that ends the layer's reads (under the wait for the slowest wave): the
+  // next layer's bias and -- when the activations this lane is about to overwrite are the residual of the block's second conv --
+  // those activations (only this lane ever writes them).  Part 2, after the barrier: inverse transform, ReLU, store in place; the
+  // next layer's accumulators start at bias (+ residual).
+  f32x4 epre[4][2];
+  uint32_t oc[4];  // the lane's 2x2 outputs (first of its channels; ct adds 64 B)
+  auto epilogue_fetch = [&](bool with_res, const float *bnext) {
     const int ln = fresh(lane), tile_ = 16 * tg + (ln & 15), kq_ = ln >> 4, ty_ = tile_ / TR, tx_ = tile_ - ty_ * TR;
     const int bo = 32 * chalf + 4 * kq_;  // first of the lane's channels (ct adds 16)
-    uint32_t oc[4];                        // the lane's 2x2 outputs
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 2 * ty_ + (i >> 1), c = 2 * tx_ + (i & 1);
       oc[i] = act0 + (uint32_t)((tile_ < NT && r < N && c < N ? wb * BOARD_BYTES + Q::cell_off(r, c) : DUMP_OFF) + bo * 4);
     }
-    f32x4 y[4][2];  // [output 2 a + b][ct] (4 channels r)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      f32x4 s0[4], s1[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        s0[q] = (acc[q][ct] + acc[4 + q][ct]) + acc[8 + q][ct];
-        s1[q] = (acc[4 + q][ct] - acc[8 + q][ct]) - acc[12 + q][ct];
-      }
-      y[0][ct] = (s0[0] + s0[1]) + s0[2];
-      y[1][ct] = (s0[1] - s0[2]) - s0[3];
-      y[2][ct] = (s1[0] + s1[1]) + s1[2];
-      y[3][ct] = (s1[1] - s1[2]) - s1[3];
-    }
-    f32x4 pre[4][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const f32x4 bv = bnext != nullptr ? *(const f32x4 *)(bnext + bo + 16 * ct) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
-        const uint32_t a = oc[o] + (uint32_t)(ct * 64);
-        f32x4 base = bv;
+        epre[o][ct] = bv;
         if (with_res) {
+          const uint32_t a = oc[o] + (uint32_t)(ct * 64);
           const f32x2 x0 = lds_r2(a), x1 = lds_r2(a + 8);
-          base = bv + (f32x4){x0[0], x0[1], x1[0], x1[1]};
+          epre[o][ct] = bv + (f32x4){x0[0], x0[1], x1[0], x1[1]};
         }
-        lds_w2(a, (f32x2){fmaxf(y[o][ct][0], 0.0f), fmaxf(y[o][ct][1], 0.0f)});
-        lds_w2(a + 8, (f32x2){fmaxf(y[o][ct][2], 0.0f), fmaxf(y[o][ct][3], 0.0f)});
-        pre[o][ct] = base;
       }
     }
-    preload(pre);
+  };
+  auto epilogue = [&]() {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      f32x4 s0[4], s1[4], y[4];  // y: [output 2 a + b] (4 channels r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s0[q] = (acc[q][ct] + acc[4 + q][ct]) + acc[8 + q][ct];
+        s1[q] = (acc[4 + q][ct] - acc[8 + q][ct]) - acc[12 + q][ct];
+      }
+      y[0] = (s0[0] + s0[1]) + s0[2];
+      y[1] = (s0[1] - s0[2]) - s0[3];
+      y[2] = (s1[0] + s1[1]) + s1[2];
+      y[3] = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const uint32_t a = oc[o] + (uint32_t)(ct * 64);
+        lds_w2(a, (f32x2){fmaxf(y[o][0], 0.0f), fmaxf(y[o][1], 0.0f)});
+        lds_w2(a + 8, (f32x2){fmaxf(y[o][2], 0.0f), fmaxf(y[o][3], 0.0f)});
+      }
+    }
+    preload(epre);
   };
 
 #if AZ_W_STAMP
@@ -485,9 +491,10 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
     WSTAMP(3);
     conv_w<2, RSB>(lds0, pb, abase, u0, L > 0 ? ul : u0, wave, lane, acc);
     WSTAMP(4);
+    epilogue_fetch(false, L > 0 ? bl + C : nullptr);
     __syncthreads();  // every wave has read the layer's input: the outputs may overwrite it
     WSTAMP(5);
-    epilogue(false, L > 0 ? bl + C : nullptr);
+    epilogue();
     WSTAMP(6);
     if (tid == 0 && L > 0 && x == nullptr) {  // the ticket to fetch ahead: the next one when any of its leaves needs the network (else it is resolved at the top)
       const int nx = slots[1];
@@ -518,15 +525,17 @@ __global__ __launch_bounds__(NTH, 2) void k_tower_f32w(const float *__restrict__
           if (tid == 0) slots[3] = pf;
         }
       }
+      epilogue_fetch(true, bl + (2 + l) * C);
       __syncthreads();
       WSTAMP(8 + 3 * l);
-      epilogue(true, bl + (2 + l) * C);
+      epilogue();
       WSTAMP(9 + 3 * l);
       conv_w<8, RSB>(lds0, pb, abase, w2, l + 2 < L ? w2 + (size_t)8 * STAGE_BYTES : u0, wave, lane, acc);
       WSTAMP(10 + 3 * l);
+      epilogue_fetch(false, l + 2 < L ? bl + (3 + l) * C : nullptr);
       __syncthreads();
       WSTAMP(11 + 3 * l);
-      epilogue(false, l + 2 < L ? bl + (3 + l) * C : nullptr);
+      epilogue();
       WSTAMP(12 + 3 * l);
     }
     __syncthreads();
