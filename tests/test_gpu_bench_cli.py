@@ -96,3 +96,29 @@ def test_bench_gpus_2_launches_two_ranks_gloo_rehearsal():
     per_rank_sims = 128 * 16 * 2
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - 2 * per_rank_sims) <= 0.02 * 2 * per_rank_sims
     assert d["throughput_mode"] is None and "one GPU" in d["throughput_mode_why"]
+
+
+def test_bench_under_torch_distributed_run_two_ranks_gloo_rehearsal():
+    """The driver's launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with two ranks: bench.py takes the ranks it is given (no launcher of its own), rank 0
+    prints the one JSON line.  (gloo rehearsal on the one-GPU box, as above; the primary line is the Winograd f32 tower.)"""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--slots", "128",
+           "--sims", "16", "--steps", "2", "--warmup", "1", "--preroll", "4", "--game-probe", "16", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0's)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["devices"] == [0, 0] and d["launched_by"].startswith("external")
+    assert d["value"] > 0 and d["dtype"] == "f32" and d["roofline"]["kernel"] == "k_tower_f32w" and d["throughput_mode"] is None
+    # and a world size that differs from --gpus is refused
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
