@@ -610,6 +610,17 @@ extern "C" int az_tower_forward_f32w(int32_t board_size, int32_t channels, int32
   }
   if ((board_size != 15 && board_size != 9) || channels != 64) { tower_set_error("Winograd f32 tower: 9x9 or 15x15 boards, 64 channels"); return AZ_EINVAL; }
   if (feat_stride < az_heads_feat_stride(board_size)) { tower_set_error("feat_stride below az_heads_feat_stride(board_size)"); return AZ_EINVAL; }
+  // what the kernel's addressing assumes: 32-bit byte offsets into the packed batch (ring records of up to 516 bytes), the weight
+  // stream and the leaf records moved 16 bytes at a time, and the look-ahead's flag read = the ALIGNED word that holds the next
+  // ticket's flag bytes (an aligned word never leaves the page its valid byte lies in; an unaligned one could)
+  if (n_boards > (1 << 22)) { tower_set_error("Winograd f32 tower: at most 4,194,304 boards per launch"); return AZ_EINVAL; }
+  auto misaligned = [](const void *p, uintptr_t a) { return p != nullptr && ((uintptr_t)p & (a - 1)) != 0; };
+  if (misaligned(x_f32_dev, 4) || misaligned(packed_ring_dev, 4) || misaligned(packed_leaf_dev, 16) || misaligned(flags_dev, 4) ||
+      misaligned(u0_dev, 16) || misaligned(ul_dev, 16) || misaligned(bias_dev, 4) || misaligned(headw_dev, 4) || misaligned(headb_dev, 4) ||
+      misaligned(feat_f32_dev, 4)) {
+    tower_set_error("Winograd f32 tower: misaligned pointer (leaf records and transformed weights: 16 bytes; everything else, the flag bytes included: 4)");
+    return AZ_EINVAL;
+  }
   hipStream_t s = (hipStream_t)stream;
   int dev = 0, cur = 0;
   if (tower_device(s, &dev) != 0 || dev < 0 || dev >= 64) { tower_set_error("cannot tell the stream's device"); return AZ_EHIP; }

@@ -276,7 +276,9 @@ int az_tower_forward_h1(int32_t board_size, int32_t channels, int32_t n_boards, 
  *   u0_dev [stage 2][j 2][kq 4][co tile 4][i 4][co 16][q 4] f32 (input channel 8 stage + 2 kq + j, 9 of 16 used; transform
  *   point (i, q); output channel 16 tile + co), ul_dev [n_conv_layers][stage 8][...] likewise;
  *   bias_dev [1 + n_conv_layers][64], headw_dev (3, 64), headb_dev (3) f32 as az_tower_forward_f32.
- * board_size 15 or 9 (two boards per workgroup), channels 64, n_conv_layers even, <= 36. */
+ * board_size 15 or 9 (two boards per workgroup), channels 64, n_conv_layers even, <= 36; 1 <= n_boards <= 4,194,304 (32-bit byte
+ * offsets into the packed batch); packed_leaf_dev, u0_dev, ul_dev 16-byte aligned, every other pointer -- flags_dev included: the
+ * look-ahead reads the aligned word that holds a ticket's flag bytes -- 4-byte aligned (AZ_EINVAL otherwise). */
 int az_tower_forward_f32w(int32_t board_size, int32_t channels, int32_t n_boards, int32_t n_conv_layers, const float *x_f32_dev,
                           const void *packed_ring_dev, const void *packed_leaf_dev, const void *flags_dev, const void *u0_dev,
                           const void *ul_dev, const float *bias_dev, const float *headw_dev, const float *headb_dev,

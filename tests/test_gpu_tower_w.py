@@ -94,3 +94,35 @@ def test_winograd_tower_refuses_what_it_does_not_cover():
     for net in (GomokuNet(9, 128, 1), GomokuNet(15, 128, 1), QuickNet(15, 15, 64, 1, 2)):
         with pytest.raises(EngineError):
             FusedTowerEvaluator(net.eval().cuda(), "f32w")
+
+
+def test_winograd_entry_point_refuses_misaligned_pointers_and_oversized_batches():
+    """the C-ABI's host-side checks of what the kernel's addressing assumes (no launch happens): flag bytes on a 4-byte boundary
+    (the look-ahead reads the aligned word that holds them), 16-byte aligned leaf records and weights, at most 2^22 boards"""
+    from alphazero_amd import Engine
+    from alphazero_amd.fused import FusedTowerEvaluator
+    from alphazero_amd.nets import GomokuNet
+
+    G = 64
+    ev = FusedTowerEvaluator(_randomised(GomokuNet(15, 64, 1)).eval().cuda(), "f32w")
+    eng = Engine(2, G, 8, board_size=15, nn_dtype=torch.float32, device="cuda:0")
+    nn = eng.new_nn_input()
+    eng.begin_search()
+    eng.select_gather(nn)
+    ring, leaf, _, _, flags = eng.leaf_buffers()
+    L, fs = ev.lib, ev.feat_stride
+    feat = torch.zeros(G, fs, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(n=G, ring=ring, leaf=leaf, flags=flags, u0=ev.w0.data_ptr(), feat=feat.data_ptr()):
+        return L.az_tower_forward_f32w(15, 64, n, ev.n_layers, None, ring, leaf, flags, u0, ev.wl.data_ptr(), ev.bias.data_ptr(),
+                                       ev.headw.data_ptr(), ev.headb.data_ptr(), feat, fs, st)
+
+    assert call() == 0
+    torch.cuda.synchronize()
+    for bad in (dict(flags=flags + 1), dict(ring=ring + 2), dict(leaf=leaf + 8), dict(u0=ev.w0.data_ptr() + 4), dict(feat=feat.data_ptr() + 2),
+                dict(n=(1 << 22) + 1), dict(n=0)):
+        assert call(**bad) == -1, bad  # AZ_EINVAL
+        assert L.az_tower_last_error()
+    eng.close()
+
