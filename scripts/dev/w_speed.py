@@ -36,7 +36,7 @@ if __name__ == "__main__":
 
     from alphazero_amd.engine import load_library
     lib = load_library()
-    if hasattr(lib, "az_debug_w_stamps"):  # a -DAZ_W_STAMP=1 build: phase boundaries of one board (workgroup 7, its sixth), s_memtime ticks (100 MHz)
+    if hasattr(lib, "az_debug_w_stamps"):  # a -DAZ_W_STAMP=1 build: phase boundaries of one board (workgroup 7, its sixth), s_memtime ticks (shader-clock cycles on this part: a board's total matches launch time / boards per workgroup at 2.39 GHz)
         ev = FusedTowerEvaluator(net, "f32w")
         ev(x.contiguous())
         torch.cuda.synchronize()
@@ -49,9 +49,9 @@ if __name__ == "__main__":
         names.update({28: "barrier", 29: "heads", 30: "barrier", 31: "feature rows"})
         for w in (0, 3, 7):
             t = [buf[w * 32 + k] for k in range(32)]
-            print(f"wave {w}: board total {(t[31] - t[0]) * 10} ns")
+            print(f"wave {w}: board total {t[31] - t[0]} cycles")
             prev = t[0]
             for k in sorted(names):
                 if t[k]:
-                    print(f"   {names[k]:>18}: +{(t[k] - prev) * 10:6d} ns")
+                    print(f"   {names[k]:>18}: +{t[k] - prev:6d} cycles")
                     prev = t[k]
